@@ -1,0 +1,221 @@
+// device_math.h -- f64 vector helpers, the counter-based RNG and the per-primitive
+// intersection tests used by the HIP kernels.
+//
+// Arithmetic contract: every expression below is written in the operand order of
+// the reference formula it cites and the translation unit is compiled with
+// -ffp-contract=off, so +,-,*,/ and sqrt produce the bits the reference's f64 code
+// produces (rustc never fuses a*b+c).  Comparisons are written as the reference
+// writes them (no fmin/fmax where it uses `<`), which keeps its NaN behaviour.
+#ifndef RT_DEVICE_MATH_H
+#define RT_DEVICE_MATH_H
+
+#include <hip/hip_runtime.h>
+#include "device_types.h"
+
+namespace rt {
+
+#define RT_DEV __device__ __forceinline__
+
+constexpr double D_INF = __builtin_huge_val();
+constexpr double D_PI = 3.1415926535897932385; // rtweekend.rs:7
+
+struct D3 { double x, y, z; };
+RT_DEV D3 d3(double x, double y, double z) { D3 r; r.x = x; r.y = y; r.z = z; return r; }
+RT_DEV D3 d3p(const double* p) { return d3(p[0], p[1], p[2]); }
+RT_DEV D3 operator+(D3 a, D3 b) { return d3(a.x + b.x, a.y + b.y, a.z + b.z); }
+RT_DEV D3 operator-(D3 a, D3 b) { return d3(a.x - b.x, a.y - b.y, a.z - b.z); }
+RT_DEV D3 operator-(D3 a) { return d3(-a.x, -a.y, -a.z); }
+RT_DEV D3 operator*(D3 a, D3 b) { return d3(a.x * b.x, a.y * b.y, a.z * b.z); }
+RT_DEV D3 operator*(double t, D3 v) { return d3(t * v.x, t * v.y, t * v.z); }
+RT_DEV D3 operator*(D3 v, double t) { return d3(t * v.x, t * v.y, t * v.z); }
+RT_DEV D3 operator/(D3 v, double t) { return (1.0 / t) * v; } // v / t == v * (1/t)
+RT_DEV double dot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RT_DEV D3 cross(D3 a, D3 b) { return d3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+RT_DEV double length_squared(D3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+RT_DEV double length(D3 a) { return sqrt(length_squared(a)); }
+RT_DEV D3 unit_vector(D3 v) { return v / length(v); }
+
+RT_DEV int32_t sat_i32(double x) { // Rust `as i32`
+    if (x != x) return 0;
+    if (x <= -2147483648.0) return INT32_MIN;
+    if (x >= 2147483647.0) return INT32_MAX;
+    return (int32_t)x;
+}
+RT_DEV uint32_t sat_u32(double x) { // Rust `as u32`
+    if (x != x || x <= 0.0) return 0u;
+    if (x >= 4294967295.0) return 0xFFFFFFFFu;
+    return (uint32_t)x;
+}
+
+// ------------------------------------------------------------------------ rng
+// Philox4x32-10; stream layout documented at rt_rng_uniform in mi355rt.h.
+__host__ __device__ inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)M0 * c[0];
+        uint64_t p1 = (uint64_t)M1 * c[2];
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += W0; k1 += W1;
+    }
+}
+
+__host__ __device__ inline double philox_uniform(uint64_t seed, uint32_t stream, uint32_t a, uint32_t b, uint64_t index) {
+    uint32_t c[4] = {(uint32_t)(index >> 1), stream, a, b};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    uint64_t bits = (index & 1) ? (((uint64_t)c[2] << 32) | c[3]) : (((uint64_t)c[0] << 32) | c[1]);
+    return (double)(bits >> 11) * (1.0 / 9007199254740992.0);
+}
+
+struct Rng { // one path's stream; `index` is the number of draws made so far
+    uint64_t seed;
+    uint32_t stream, a, b;
+    uint32_t index;
+    RT_DEV double next() { return philox_uniform(seed, stream, a, b, index++); }                // rtweekend.rs:15-17
+    RT_DEV double range(double lo, double hi) { return lo + (hi - lo) * next(); }               // rtweekend.rs:19-21
+    RT_DEV int32_t random_int(int32_t lo, int32_t hi) { return sat_i32(range((double)lo, (double)(hi + 1))); } // rtweekend.rs:23-25
+};
+
+RT_DEV D3 random_unit_vector(Rng& g) { // material.rs:146, pdf.rs:37
+    for (;;) {
+        double a = g.range(-1.0, 1.0);
+        double b = g.range(-1.0, 1.0);
+        double c = g.range(-1.0, 1.0);
+        D3 p = d3(a, b, c);
+        double lensq = length_squared(p);
+        if (1e-160 < lensq && lensq <= 1.0) return p / sqrt(lensq);
+    }
+}
+RT_DEV D3 random_in_unit_disk(Rng& g) { // camera.rs:238
+    for (;;) {
+        double a = g.range(-1.0, 1.0);
+        double b = g.range(-1.0, 1.0);
+        D3 p = d3(a, b, 0.0);
+        if (length_squared(p) < 1.0) return p;
+    }
+}
+RT_DEV D3 random_cosine_direction(Rng& g) { // pdf.rs:58
+    double r1 = g.next();
+    double r2 = g.next();
+    double phi = 2.0 * D_PI * r1;
+    double x = cos(phi) * sqrt(r2);
+    double y = sin(phi) * sqrt(r2);
+    double z = sqrt(1.0 - r2);
+    return d3(x, y, z);
+}
+RT_DEV D3 reflect(D3 v, D3 n) { return v - 2.0 * dot(v, n) * n; } // material.rs:145,209
+RT_DEV D3 refract(D3 uv, D3 n, double etai_over_etat) {           // material.rs:211
+    double cos_theta = fmin(dot(-uv, n), 1.0);
+    D3 r_out_perp = etai_over_etat * (uv + cos_theta * n);
+    D3 r_out_parallel = -sqrt(fabs(1.0 - length_squared(r_out_perp))) * n;
+    return r_out_perp + r_out_parallel;
+}
+
+struct Onb { // onb.rs:3-39
+    D3 a0, a1, a2;
+    RT_DEV explicit Onb(D3 n) {
+        a2 = unit_vector(n);
+        D3 a = fabs(a2.x) > 0.9 ? d3(0.0, 1.0, 0.0) : d3(1.0, 0.0, 0.0);
+        a1 = unit_vector(cross(a2, a));
+        a0 = cross(a2, a1);
+    }
+    RT_DEV D3 transform(D3 v) const { return a0 * v.x + a1 * v.y + a2 * v.z; }
+};
+
+// ----------------------------------------------------------------------- rays
+struct RayD { // a ray in the coordinates of the current transform context
+    double ox, oy, oz, dx, dy, dz;
+    double ix, iy, iz; // 1/d per axis: the value aabb.rs:88 recomputes at every node
+};
+RT_DEV void set_inverse(RayD& r) { r.ix = 1.0 / r.dx; r.iy = 1.0 / r.dy; r.iz = 1.0 / r.dz; }
+
+// Aabb::hit (aabb.rs:82-107) on bounds = xmin xmax ymin ymax zmin zmax.
+RT_DEV bool slab_test(const double* b, const RayD& r, double lo, double hi) {
+    {
+        double t0 = (b[0] - r.ox) * r.ix, t1 = (b[1] - r.ox) * r.ix;
+        double tmn = t0 < t1 ? t0 : t1, tmx = t0 < t1 ? t1 : t0;
+        if (tmn > lo) lo = tmn;
+        if (tmx < hi) hi = tmx;
+        if (hi <= lo) return false;
+    }
+    {
+        double t0 = (b[2] - r.oy) * r.iy, t1 = (b[3] - r.oy) * r.iy;
+        double tmn = t0 < t1 ? t0 : t1, tmx = t0 < t1 ? t1 : t0;
+        if (tmn > lo) lo = tmn;
+        if (tmx < hi) hi = tmx;
+        if (hi <= lo) return false;
+    }
+    {
+        double t0 = (b[4] - r.oz) * r.iz, t1 = (b[5] - r.oz) * r.iz;
+        double tmn = t0 < t1 ? t0 : t1, tmx = t0 < t1 ? t1 : t0;
+        if (tmn > lo) lo = tmn;
+        if (tmx < hi) hi = tmx;
+        if (hi <= lo) return false;
+    }
+    return true;
+}
+
+// Sphere::hit (sphere.rs:72-98): the accepted root, open interval (tmin, tmax).
+RT_DEV bool sphere_test(const DSphere& s, const RayD& r, double time, double tmin, double tmax, double& t_out) {
+    D3 center = d3(s.c[0], s.c[1], s.c[2]) + time * d3(s.dc[0], s.dc[1], s.dc[2]);
+    D3 o = d3(r.ox, r.oy, r.oz), d = d3(r.dx, r.dy, r.dz);
+    D3 oc = center - o;
+    double a = length_squared(d);
+    double h = dot(d, oc);
+    double c = length_squared(oc) - s.radius * s.radius;
+    double discriminant = h * h - a * c;
+    if (discriminant < 0.0) return false;
+    double sqrtd = sqrt(discriminant);
+    double root = (h - sqrtd) / a;
+    if (!(tmin < root && root < tmax)) {
+        root = (h + sqrtd) / a;
+        if (!(tmin < root && root < tmax)) return false;
+    }
+    t_out = root;
+    return true;
+}
+
+// Quad::hit (quad.rs:76-103): closed interval [tmin, tmax]; alpha/beta returned for rec.u/v.
+RT_DEV bool quad_test(const DQuad& qd, const RayD& r, double tmin, double tmax, double& t_out, double& alpha, double& beta) {
+    D3 n = d3(qd.n[0], qd.n[1], qd.n[2]);
+    D3 o = d3(r.ox, r.oy, r.oz), d = d3(r.dx, r.dy, r.dz);
+    double denom = dot(n, d);
+    if (fabs(denom) < 1e-8) return false;
+    double t = (qd.d - dot(n, o)) / denom;
+    if (!(tmin <= t && t <= tmax)) return false;
+    D3 intersection = o + t * d;
+    D3 hp = intersection - d3(qd.q[0], qd.q[1], qd.q[2]);
+    D3 w = d3(qd.w[0], qd.w[1], qd.w[2]);
+    alpha = dot(w, cross(hp, d3(qd.v[0], qd.v[1], qd.v[2])));
+    beta = dot(w, cross(d3(qd.u[0], qd.u[1], qd.u[2]), hp));
+    if (!(0.0 <= alpha && alpha <= 1.0) || !(0.0 <= beta && beta <= 1.0)) return false;
+    t_out = t;
+    return true;
+}
+
+// Triangle::hit (triangle.rs:153-188): Moeller-Trumbore with edges recomputed per call.
+RT_DEV bool tri_test(D3 v0, D3 v1, D3 v2, const RayD& r, double tmin, double tmax, double& t_out, double& u_out, double& v_out) {
+    D3 o = d3(r.ox, r.oy, r.oz), d = d3(r.dx, r.dy, r.dz);
+    D3 edge1 = v1 - v0, edge2 = v2 - v0;
+    D3 h = cross(d, edge2);
+    double a = dot(edge1, h);
+    if (fabs(a) < 1e-8) return false;
+    double f = 1.0 / a;
+    D3 s = o - v0;
+    double u = f * dot(s, h);
+    if (u < 0.0 || u > 1.0) return false;
+    D3 q = cross(s, edge1);
+    double v = f * dot(d, q);
+    if (v < 0.0 || u + v > 1.0) return false;
+    double t = f * dot(edge2, q);
+    if (!(tmin <= t && t <= tmax)) return false;
+    t_out = t; u_out = u; v_out = v;
+    return true;
+}
+
+} // namespace rt
+#endif

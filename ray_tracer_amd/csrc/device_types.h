@@ -1,0 +1,117 @@
+// device_types.h -- layout of the flattened scene in HBM, shared by the host
+// flattener (flatten.cpp) and the HIP kernels (mi355rt.hip).
+//
+// Every record that a traversal lane fetches on its own is a multiple of 16 bytes
+// and 16-byte aligned, so one lane reads it with dwordx4 loads; BVH nodes are one
+// 64-byte record (half a 128-byte line, never straddling one).
+#ifndef RT_DEVICE_TYPES_H
+#define RT_DEVICE_TYPES_H
+
+#include <stdint.h>
+#include "../../include/mi355rt.h"
+
+namespace rt {
+
+// Internal reference kinds that only live on the traversal stack.
+constexpr uint32_t REF_LISTCONT = 8u;  // resume list `index` at the position stored one entry below
+constexpr uint32_t REF_POPX = 9u;      // leave a transform: restore context `index`
+constexpr uint32_t REF_OTHER = 15u;    // light-list member without pdf_value/random (hittable.rs:51-56 defaults)
+
+constexpr int STACK_MAX = 32;          // traversal stack entries per lane (LDS)
+constexpr int XFORM_DEPTH_MAX = 8;     // nested Translate/RotateY levels
+
+inline constexpr uint32_t make_ref(uint32_t kind, uint32_t index) { return (kind << 28) | (index & 0x0FFFFFFFu); }
+
+struct alignas(16) DSphere {   // 64 B (sphere.rs:12-17; center is the ray center1 + t*(center2-center1))
+    double c[3];
+    double dc[3];
+    double radius;
+    int32_t mat;
+    int32_t _pad;
+};
+
+struct alignas(16) DQuad {     // 144 B (quad.rs:15-25 without the bbox)
+    double q[3];
+    double u[3];
+    double v[3];
+    double w[3];
+    double n[3];               // unit normal
+    double d;
+    double area;
+    int32_t mat;
+    int32_t _pad;
+};
+
+struct alignas(8) DTri {       // 72 B: the three vertices the intersector reads (triangle.rs:113-115)
+    double v0[3];
+    double v1[3];
+    double v2[3];
+};
+
+struct alignas(16) DTriAux {   // 32 B: read once per accepted hit
+    double n[3];               // unit normal (triangle.rs:125)
+    int32_t mat;
+    int32_t _pad;
+};
+
+typedef rt_bvh_node DNode;     // 64 B
+
+struct DList { uint32_t first, count; };
+
+struct alignas(8) DXform {     // hittable.rs:61-65 / 97-102
+    int32_t kind;              // 0 translate (a = offset), 1 rotate_y (a[0] = sin, a[1] = cos)
+    int32_t parent;            // context id of the enclosing transform chain (0 = world)
+    uint32_t child;
+    int32_t depth;             // number of transforms from the world to here (>= 1)
+    double a[3];
+};
+
+struct alignas(8) DMedium {    // constant_medium.rs:14-18
+    uint32_t boundary;
+    int32_t mat;
+    double neg_inv_density;
+    int32_t object;            // object id in the description (reported as the primitive index)
+    int32_t _pad;
+};
+
+struct alignas(8) DMaterial {
+    int32_t kind;
+    int32_t tex;
+    double albedo[3];
+    double fuzz;
+    double ior;
+};
+
+struct alignas(8) DTexture {
+    int32_t kind, even, odd, image, perlin, _pad;
+    double color[3];
+    double scale;              // CHECKER: inv_scale = 1/scale (texture.rs:43); NOISE: scale
+};
+
+struct DLight { uint32_t kind; uint32_t index; }; // RT_REF_SPHERE / RT_REF_QUAD / REF_OTHER
+
+// Pointers are device pointers once uploaded (host pointers in a HOST_ONLY scene).
+struct DScene {
+    const DNode* nodes;
+    const DSphere* spheres;
+    const DQuad* quads;
+    const DTri* tris;
+    const DTriAux* tri_aux;
+    const DList* lists;
+    const uint32_t* list_items;
+    const DXform* xforms;
+    const DMedium* media;
+    const DMaterial* materials;
+    const DTexture* textures;
+    const rt_image* images;
+    const uint8_t* image_bytes;
+    const rt_perlin* perlins;
+    const DLight* lights;
+    uint32_t world;
+    int32_t n_lights;          // -1: no light list (material pdf only)
+    int32_t lights_is_list;    // 1: HittableList semantics (uniform pick / mean pdf), 0: a single object
+    int32_t _pad;
+};
+
+} // namespace rt
+#endif

@@ -1,0 +1,591 @@
+// flatten.cpp -- host flattener (no HIP in this file).
+//
+// Turns the declarative object graph of rt_scene_desc into the linear arrays the
+// kernels traverse.  What it must reproduce from the reference so that closest-hit
+// results can be compared one-to-one:
+//   - bounding boxes of every Hittable: sphere.rs:25-45, quad.rs:51-61,
+//     triangle.rs:127-139, hittable_list.rs:37-40, hittable.rs:67-76,104-143,
+//     constant_medium.rs:106-108, obj_loader.rs:103-105, with the padding rule of
+//     aabb.rs:125-136 applied exactly where the reference applies it;
+//   - the BVH split order of BvhNode::from_objects (bvh.rs:20-77): bbox = union over
+//     the span, axis = Aabb::longest_axis (aabb.rs:109-123), STABLE sort on
+//     bbox.axis(axis).min, mid = start + span/2, span 1 -> both children are the same
+//     object, span 2 -> the pair in incoming order;
+//   - the precomputed quad / triangle constants (quad.rs:28-49, triangle.rs:122-125).
+// Nodes of one BVH are laid out in pre-order (left child = index + 1).
+#include "flatten.h"
+
+#include <algorithm>
+#include <cmath>
+#include <future>
+#include <limits>
+#include <map>
+#include <numeric>
+
+namespace rt {
+namespace {
+
+const double INF = std::numeric_limits<double>::infinity();
+const double PI = 3.1415926535897932385; // rtweekend.rs:7
+
+struct V3 { double x, y, z; };
+inline V3 v3(const double* p) { return V3{p[0], p[1], p[2]}; }
+inline V3 add(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline V3 sub(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 scale(double t, V3 v) { return V3{t * v.x, t * v.y, t * v.z}; }
+inline double dot3(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline V3 cross3(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline double len3(V3 a) { return std::sqrt(dot3(a, a)); }
+inline V3 divs(V3 v, double t) { return scale(1.0 / t, v); } // v / t == v * (1/t)
+inline V3 unit3(V3 v) { return divs(v, len3(v)); }
+inline void put(double* o, V3 v) { o[0] = v.x; o[1] = v.y; o[2] = v.z; }
+
+inline Box box_empty() { return Box{{INF, -INF, INF, -INF, INF, -INF}}; } // interval.rs:12-15
+inline void pad_axis(double& lo, double& hi) {                             // aabb.rs:125-136, interval.rs:75-81
+    const double delta = 0.0001;
+    if (hi - lo < delta) { double p = delta / 2.0; lo = lo - p; hi = hi + p; }
+}
+inline Box box_from_points(V3 a, V3 b) { // aabb.rs:43-63
+    Box r;
+    if (a.x <= b.x) { r.b[0] = a.x; r.b[1] = b.x; } else { r.b[0] = b.x; r.b[1] = a.x; }
+    if (a.y <= b.y) { r.b[2] = a.y; r.b[3] = b.y; } else { r.b[2] = b.y; r.b[3] = a.y; }
+    if (a.z <= b.z) { r.b[4] = a.z; r.b[5] = b.z; } else { r.b[4] = b.z; r.b[5] = a.z; }
+    pad_axis(r.b[0], r.b[1]); pad_axis(r.b[2], r.b[3]); pad_axis(r.b[4], r.b[5]);
+    return r;
+}
+inline Box box_union(const Box& a, const Box& b) { // aabb.rs:65-71, interval.rs:43-48
+    Box r;
+    for (int k = 0; k < 3; ++k) {
+        r.b[2 * k] = std::fmin(a.b[2 * k], b.b[2 * k]);
+        r.b[2 * k + 1] = std::fmax(a.b[2 * k + 1], b.b[2 * k + 1]);
+    }
+    return r;
+}
+inline int longest_axis(const Box& a) { // aabb.rs:109-123
+    double sx = a.b[1] - a.b[0], sy = a.b[3] - a.b[2], sz = a.b[5] - a.b[4];
+    if (sx > sy) return sx > sz ? 0 : 2;
+    return sy > sz ? 1 : 2;
+}
+inline bool box_has_nan(const Box& a) {
+    for (double v : a.b) if (v != v) return true;
+    return false;
+}
+
+struct Item { Box box; uint32_t ref; uint32_t medium; };
+
+uint64_t bvh_node_count(uint64_t n) { // N(1)=N(2)=1, N(n)=1+N(n/2)+N(n-n/2)
+    if (n <= 2) return 1;
+    return 1 + bvh_node_count(n / 2) + bvh_node_count(n - n / 2);
+}
+
+// Builds the subtree for items[start,end) into nodes[at ...]; returns has-medium flag.
+uint32_t build_bvh(std::vector<Item>& items, size_t start, size_t end, DNode* nodes, uint64_t base, uint64_t at, int depth) {
+    size_t span = end - start;
+    Box bbox = box_empty();
+    for (size_t i = start; i < end; ++i) bbox = box_union(bbox, items[i].box);
+    int axis = longest_axis(bbox);
+    DNode& n = nodes[at];
+    for (int k = 0; k < 6; ++k) n.bounds[k] = bbox.b[k];
+    n._pad = 0;
+    uint32_t medium = 0;
+    if (span == 1) {
+        n.left = n.right = items[start].ref;
+        medium = items[start].medium;
+    } else if (span == 2) {
+        n.left = items[start].ref;
+        n.right = items[start + 1].ref;
+        medium = items[start].medium | items[start + 1].medium;
+    } else {
+        std::vector<uint32_t> order(span);
+        std::iota(order.begin(), order.end(), 0u);
+        const Item* base_items = items.data() + start;
+        std::stable_sort(order.begin(), order.end(), [base_items, axis](uint32_t a, uint32_t b) {
+            return base_items[a].box.b[2 * axis] < base_items[b].box.b[2 * axis];
+        });
+        {
+            std::vector<Item> sorted(span);
+            for (size_t i = 0; i < span; ++i) sorted[i] = base_items[order[i]];
+            std::copy(sorted.begin(), sorted.end(), items.begin() + start);
+        }
+        size_t mid = start + span / 2;
+        uint64_t left_at = at + 1;
+        uint64_t right_at = left_at + bvh_node_count(mid - start);
+        n.left = make_ref(RT_REF_NODE, (uint32_t)(base + left_at));
+        n.right = make_ref(RT_REF_NODE, (uint32_t)(base + right_at));
+        uint32_t ml, mr;
+        if (depth < 4 && span > 8192) { // the two halves are independent (bvh.rs:64-67 uses rayon::join)
+            auto fut = std::async(std::launch::async, [&]() { return build_bvh(items, start, mid, nodes, base, left_at, depth + 1); });
+            mr = build_bvh(items, mid, end, nodes, base, right_at, depth + 1);
+            ml = fut.get();
+        } else {
+            ml = build_bvh(items, start, mid, nodes, base, left_at, depth + 1);
+            mr = build_bvh(items, mid, end, nodes, base, right_at, depth + 1);
+        }
+        medium = ml | mr;
+    }
+    n.flags = medium ? 1u : 0u;
+    return medium;
+}
+
+struct Flattener {
+    const rt_scene_desc* d;
+    FlatScene& f;
+    std::string& err;
+    std::map<std::pair<int32_t, int32_t>, uint32_t> memo; // (object, ctx) -> ref
+    std::vector<uint8_t> obj_medium;                     // object subtree contains a medium
+    std::vector<int32_t> need_node;
+
+    Flattener(const rt_scene_desc* desc, FlatScene& out, std::string& e) : d(desc), f(out), err(e) {}
+
+    int fail(int code, const std::string& m) { err = m; return code; }
+
+    int check_textures() {
+        for (uint64_t i = 0; i < d->n_textures; ++i) {
+            const rt_texture& t = d->textures[i];
+            DTexture o{};
+            o.kind = t.kind; o.even = t.even; o.odd = t.odd; o.image = t.image; o.perlin = t.perlin;
+            o.color[0] = t.color[0]; o.color[1] = t.color[1]; o.color[2] = t.color[2];
+            o.scale = t.scale;
+            switch (t.kind) {
+            case RT_TEX_SOLID: break;
+            case RT_TEX_CHECKER:
+                if (t.even < 0 || t.odd < 0 || (uint64_t)t.even >= d->n_textures || (uint64_t)t.odd >= d->n_textures)
+                    return fail(RT_E_INVALID, "checker texture: child texture out of range");
+                // A checker only nests textures created before it (Arc ownership makes cycles impossible in the reference).
+                if ((uint64_t)t.even >= i || (uint64_t)t.odd >= i) return fail(RT_E_INVALID, "checker texture: children must precede it");
+                o.scale = 1.0 / t.scale; // inv_scale (texture.rs:43)
+                break;
+            case RT_TEX_IMAGE:
+                if (t.image >= 0) {
+                    if ((uint64_t)t.image >= d->n_images) return fail(RT_E_INVALID, "image texture: image out of range");
+                    const rt_image& im = d->images[t.image];
+                    if (im.width < 0 || im.height < 0 || im.offset + (uint64_t)im.width * (uint64_t)im.height * 3 > d->n_image_bytes)
+                        return fail(RT_E_INVALID, "image texture: pixel data out of range");
+                }
+                break;
+            case RT_TEX_NOISE:
+                if (t.perlin < 0 || (uint64_t)t.perlin >= d->n_perlins) return fail(RT_E_INVALID, "noise texture: perlin table out of range");
+                break;
+            default: return fail(RT_E_INVALID, "texture: unknown kind");
+            }
+            f.textures.push_back(o);
+        }
+        for (uint64_t i = 0; i < d->n_perlins; ++i)
+            for (int k = 0; k < 256; ++k) {
+                const rt_perlin& p = d->perlins[i];
+                if ((p.perm_x[k] | p.perm_y[k] | p.perm_z[k]) & ~255) return fail(RT_E_INVALID, "perlin: permutation entry outside 0..255");
+            }
+        return RT_OK;
+    }
+
+    bool texture_uses_uv(int32_t tex) const {
+        const rt_texture& t = d->textures[tex];
+        if (t.kind == RT_TEX_IMAGE) return true;
+        if (t.kind == RT_TEX_CHECKER) return texture_uses_uv(t.even) || texture_uses_uv(t.odd);
+        return false;
+    }
+
+    int check_materials() {
+        for (uint64_t i = 0; i < d->n_materials; ++i) {
+            const rt_material& m = d->materials[i];
+            DMaterial o{};
+            o.kind = m.kind; o.tex = m.tex;
+            o.albedo[0] = m.albedo[0]; o.albedo[1] = m.albedo[1]; o.albedo[2] = m.albedo[2];
+            o.fuzz = std::fmin(m.fuzz, 1.0); // material.rs:127-132
+            o.ior = m.ior;
+            switch (m.kind) {
+            case RT_MAT_LAMBERTIAN: case RT_MAT_DIFFUSE_LIGHT: case RT_MAT_ISOTROPIC:
+                if (m.tex < 0 || (uint64_t)m.tex >= d->n_textures) return fail(RT_E_INVALID, "material: texture out of range");
+                break;
+            case RT_MAT_METAL: case RT_MAT_DIELECTRIC: break;
+            default: return fail(RT_E_INVALID, "material: unknown kind");
+            }
+            f.materials.push_back(o);
+        }
+        return RT_OK;
+    }
+
+    bool mat_ok(int32_t m) const { return m >= 0 && (uint64_t)m < d->n_materials; }
+
+    int build_primitives() {
+        f.spheres.resize(d->n_spheres);
+        for (uint64_t i = 0; i < d->n_spheres; ++i) {
+            const rt_sphere& s = d->spheres[i];
+            if (!mat_ok(s.mat)) return fail(RT_E_INVALID, "sphere: material out of range");
+            DSphere& o = f.spheres[i];
+            V3 c1 = v3(s.center);
+            put(o.c, c1);
+            if (s.moving) put(o.dc, sub(v3(s.center2), c1)); // sphere.rs:40
+            else put(o.dc, V3{0.0, 0.0, 0.0});               // sphere.rs:28
+            o.radius = std::fmax(s.radius, 0.0);             // sphere.rs:29
+            o.mat = s.mat; o._pad = 0;
+        }
+        f.quads.resize(d->n_quads);
+        for (uint64_t i = 0; i < d->n_quads; ++i) { // quad.rs:28-49
+            const rt_quad& s = d->quads[i];
+            if (!mat_ok(s.mat)) return fail(RT_E_INVALID, "quad: material out of range");
+            DQuad& o = f.quads[i];
+            V3 q = v3(s.q), u = v3(s.u), v = v3(s.v);
+            V3 n = cross3(u, v);
+            V3 normal = unit3(n);
+            put(o.q, q); put(o.u, u); put(o.v, v);
+            put(o.n, normal);
+            o.d = dot3(normal, q);
+            put(o.w, divs(n, dot3(n, n)));
+            o.area = len3(n);
+            o.mat = s.mat; o._pad = 0;
+        }
+        f.tris.resize(d->n_triangles);
+        f.tri_aux.resize(d->n_triangles);
+        for (uint64_t i = 0; i < d->n_triangles; ++i) { // triangle.rs:122-125
+            const rt_triangle& s = d->triangles[i];
+            if (!mat_ok(s.mat)) return fail(RT_E_INVALID, "triangle: material out of range");
+            DTri& o = f.tris[i];
+            V3 v0 = v3(s.v0), v1 = v3(s.v1), v2 = v3(s.v2);
+            put(o.v0, v0); put(o.v1, v1); put(o.v2, v2);
+            put(f.tri_aux[i].n, unit3(cross3(sub(v1, v0), sub(v2, v0))));
+            f.tri_aux[i].mat = s.mat; f.tri_aux[i]._pad = 0;
+        }
+        return RT_OK;
+    }
+
+    Box sphere_box(uint64_t i) const { // sphere.rs:26-44
+        const rt_sphere& s = d->spheres[i];
+        V3 rvec{s.radius, s.radius, s.radius};
+        V3 c1 = v3(s.center);
+        Box b1 = box_from_points(sub(c1, rvec), add(c1, rvec));
+        if (!s.moving) return b1;
+        V3 c2 = v3(s.center2);
+        return box_union(b1, box_from_points(sub(c2, rvec), add(c2, rvec)));
+    }
+    Box quad_box(uint64_t i) const { // quad.rs:51-61
+        const rt_quad& s = d->quads[i];
+        V3 q = v3(s.q), u = v3(s.u), v = v3(s.v);
+        V3 p1 = q, p2 = add(q, u), p3 = add(q, v), p4 = add(add(q, u), v);
+        return box_union(box_from_points(p1, p4), box_from_points(p2, p3));
+    }
+    Box tri_box(uint64_t i) const { // triangle.rs:127-139
+        const rt_triangle& s = d->triangles[i];
+        V3 mn{std::fmin(std::fmin(s.v0[0], s.v1[0]), s.v2[0]), std::fmin(std::fmin(s.v0[1], s.v1[1]), s.v2[1]), std::fmin(std::fmin(s.v0[2], s.v1[2]), s.v2[2])};
+        V3 mx{std::fmax(std::fmax(s.v0[0], s.v1[0]), s.v2[0]), std::fmax(std::fmax(s.v0[1], s.v1[1]), s.v2[1]), std::fmax(std::fmax(s.v0[2], s.v1[2]), s.v2[2])};
+        return box_from_points(mn, mx);
+    }
+
+    // bounding_box() of every object, in id order (children have smaller ids).
+    int compute_bounds() {
+        f.object_bounds.resize(d->n_objects);
+        obj_medium.assign(d->n_objects, 0);
+        for (uint64_t i = 0; i < d->n_objects; ++i) {
+            const rt_object& o = d->objects[i];
+            Box b = box_empty();
+            auto child_ok = [&](int32_t c) { return c >= 0 && (uint64_t)c < i; };
+            switch (o.kind) {
+            case RT_OBJ_SPHERE: if (o.a < 0 || (uint64_t)o.a >= d->n_spheres) return fail(RT_E_INVALID, "object: sphere index out of range"); b = sphere_box(o.a); break;
+            case RT_OBJ_QUAD: if (o.a < 0 || (uint64_t)o.a >= d->n_quads) return fail(RT_E_INVALID, "object: quad index out of range"); b = quad_box(o.a); break;
+            case RT_OBJ_TRIANGLE: if (o.a < 0 || (uint64_t)o.a >= d->n_triangles) return fail(RT_E_INVALID, "object: triangle index out of range"); b = tri_box(o.a); break;
+            case RT_OBJ_LIST: case RT_OBJ_BVH: {
+                if (o.a < 0 || o.b < 0) return fail(RT_E_INVALID, "object: negative child range");
+                uint64_t limit = 0;
+                switch (o.child_kind) {
+                case RT_CHILD_OBJECTS: limit = d->n_children; break;
+                case RT_CHILD_SPHERES: limit = d->n_spheres; break;
+                case RT_CHILD_QUADS: limit = d->n_quads; break;
+                case RT_CHILD_TRIANGLES: limit = d->n_triangles; break;
+                default: return fail(RT_E_INVALID, "object: unknown child kind");
+                }
+                if ((uint64_t)o.a + (uint64_t)o.b > limit) return fail(RT_E_INVALID, "object: child range out of bounds");
+                if (o.kind == RT_OBJ_BVH && o.b == 0) return fail(RT_E_INVALID, "bvh: built over an empty list (the reference indexes objects[0] and panics)");
+                for (int32_t k = 0; k < o.b; ++k) { // hittable_list.rs:37-40 / bvh.rs:27-30: plain union, no padding
+                    uint64_t idx = (uint64_t)o.a + (uint64_t)k;
+                    if (o.child_kind == RT_CHILD_OBJECTS) {
+                        int32_t c = d->children[idx];
+                        if (!child_ok(c)) return fail(RT_E_INVALID, "object: a child must have a smaller id than its parent");
+                        b = box_union(b, f.object_bounds[c]);
+                        obj_medium[i] |= obj_medium[c];
+                    } else if (o.child_kind == RT_CHILD_SPHERES) b = box_union(b, sphere_box(idx));
+                    else if (o.child_kind == RT_CHILD_QUADS) b = box_union(b, quad_box(idx));
+                    else b = box_union(b, tri_box(idx));
+                }
+                break;
+            }
+            case RT_OBJ_TRANSLATE: { // hittable.rs:68-69, aabb.rs:138-145
+                if (!child_ok(o.a)) return fail(RT_E_INVALID, "translate: bad child");
+                const Box& c = f.object_bounds[o.a];
+                for (int k = 0; k < 3; ++k) { b.b[2 * k] = c.b[2 * k] + o.param[k]; b.b[2 * k + 1] = c.b[2 * k + 1] + o.param[k]; }
+                obj_medium[i] = obj_medium[o.a];
+                break;
+            }
+            case RT_OBJ_ROTATE_Y: { // hittable.rs:105-134
+                if (!child_ok(o.a)) return fail(RT_E_INVALID, "rotate_y: bad child");
+                const Box& c = f.object_bounds[o.a];
+                double radians = o.param[0] * (PI / 180.0); // f64::to_radians
+                double sin_theta = std::sin(radians), cos_theta = std::cos(radians);
+                double mn[3] = {INF, INF, INF}, mx[3] = {-INF, -INF, -INF};
+                for (int ii = 0; ii < 2; ++ii)
+                    for (int jj = 0; jj < 2; ++jj)
+                        for (int kk = 0; kk < 2; ++kk) {
+                            double x = ii == 0 ? c.b[0] : c.b[1];
+                            double y = jj == 0 ? c.b[2] : c.b[3];
+                            double z = kk == 0 ? c.b[4] : c.b[5];
+                            double newx = cos_theta * x + sin_theta * z;
+                            double newz = -sin_theta * x + cos_theta * z;
+                            double t[3] = {newx, y, newz};
+                            for (int cc = 0; cc < 3; ++cc) { mn[cc] = std::fmin(mn[cc], t[cc]); mx[cc] = std::fmax(mx[cc], t[cc]); }
+                        }
+                b = box_from_points(V3{mn[0], mn[1], mn[2]}, V3{mx[0], mx[1], mx[2]});
+                obj_medium[i] = obj_medium[o.a];
+                break;
+            }
+            case RT_OBJ_CONSTANT_MEDIUM: // constant_medium.rs:106-108
+                if (!child_ok(o.a)) return fail(RT_E_INVALID, "constant_medium: bad boundary");
+                if (!mat_ok(o.mat)) return fail(RT_E_INVALID, "constant_medium: material out of range");
+                if (obj_medium[o.a]) return fail(RT_E_UNSUPPORTED, "constant_medium: a medium inside the boundary of a medium is not supported");
+                if (d->materials[o.mat].kind == RT_MAT_ISOTROPIC && texture_uses_uv(d->materials[o.mat].tex))
+                    return fail(RT_E_UNSUPPORTED, "constant_medium: the reference never writes u,v for a medium hit (constant_medium.rs:96-101); "
+                                                  "a phase function with an image texture would read stale values and is not supported");
+                b = f.object_bounds[o.a];
+                obj_medium[i] = 1;
+                break;
+            case RT_OBJ_OBJMODEL: { // obj_loader.rs:38-39,70-71,103-105
+                if (o.a < 0 || o.b < 0 || (uint64_t)o.a + (uint64_t)o.b > d->n_triangles) return fail(RT_E_INVALID, "objmodel: triangle range out of bounds");
+                double mn[3] = {INF, INF, INF}, mx[3] = {-INF, -INF, -INF};
+                for (int32_t k = 0; k < o.b; ++k) {
+                    const rt_triangle& t = d->triangles[o.a + k];
+                    const double* vs[3] = {t.v0, t.v1, t.v2};
+                    for (auto* vv : vs)
+                        for (int cc = 0; cc < 3; ++cc) { mn[cc] = std::fmin(mn[cc], vv[cc]); mx[cc] = std::fmax(mx[cc], vv[cc]); }
+                }
+                b = box_from_points(V3{mn[0], mn[1], mn[2]}, V3{mx[0], mx[1], mx[2]});
+                break;
+            }
+            default: return fail(RT_E_INVALID, "object: unknown kind");
+            }
+            f.object_bounds[i] = b;
+        }
+        return RT_OK;
+    }
+
+    // Children of a LIST / BVH object as (box, ref, medium) items, flattened under context `ctx`.
+    int gather_items(const rt_object& o, int32_t ctx, std::vector<Item>& items) {
+        items.resize((size_t)o.b);
+        for (int32_t k = 0; k < o.b; ++k) {
+            uint64_t idx = (uint64_t)o.a + (uint64_t)k;
+            Item& it = items[(size_t)k];
+            it.medium = 0;
+            switch (o.child_kind) {
+            case RT_CHILD_OBJECTS: {
+                int32_t c = d->children[idx];
+                uint32_t r;
+                int rc = flatten_object(c, ctx, r);
+                if (rc) return rc;
+                it.ref = r; it.box = f.object_bounds[c]; it.medium = obj_medium[c];
+                break;
+            }
+            case RT_CHILD_SPHERES: it.ref = make_ref(RT_REF_SPHERE, (uint32_t)idx); it.box = sphere_box(idx); break;
+            case RT_CHILD_QUADS: it.ref = make_ref(RT_REF_QUAD, (uint32_t)idx); it.box = quad_box(idx); break;
+            default: it.ref = make_ref(RT_REF_TRI, (uint32_t)idx); it.box = tri_box(idx); break;
+            }
+        }
+        return RT_OK;
+    }
+
+    int flatten_object(int32_t id, int32_t ctx, uint32_t& out) {
+        auto key = std::make_pair(id, ctx);
+        auto it = memo.find(key);
+        if (it != memo.end()) { out = it->second; return RT_OK; }
+        const rt_object& o = d->objects[id];
+        uint32_t ref = RT_REF_NONE;
+        switch (o.kind) {
+        case RT_OBJ_SPHERE: ref = make_ref(RT_REF_SPHERE, (uint32_t)o.a); break;
+        case RT_OBJ_QUAD: ref = make_ref(RT_REF_QUAD, (uint32_t)o.a); break;
+        case RT_OBJ_TRIANGLE: ref = make_ref(RT_REF_TRI, (uint32_t)o.a); break;
+        case RT_OBJ_LIST: {
+            std::vector<Item> items;
+            int rc = gather_items(o, ctx, items);
+            if (rc) return rc;
+            DList l{(uint32_t)f.list_items.size(), (uint32_t)items.size()};
+            for (auto& i2 : items) f.list_items.push_back(i2.ref);
+            ref = make_ref(RT_REF_LIST, (uint32_t)f.lists.size());
+            f.lists.push_back(l);
+            break;
+        }
+        case RT_OBJ_OBJMODEL: {
+            DList l{(uint32_t)f.list_items.size(), (uint32_t)o.b};
+            for (int32_t k = 0; k < o.b; ++k) f.list_items.push_back(make_ref(RT_REF_TRI, (uint32_t)(o.a + k)));
+            ref = make_ref(RT_REF_LIST, (uint32_t)f.lists.size());
+            f.lists.push_back(l);
+            break;
+        }
+        case RT_OBJ_BVH: {
+            std::vector<Item> items;
+            int rc = gather_items(o, ctx, items);
+            if (rc) return rc;
+            for (auto& i2 : items)
+                if (box_has_nan(i2.box)) return fail(RT_E_INVALID, "bvh: NaN in a bounding box (the reference panics in partial_cmp().unwrap(), bvh.rs:90-93)");
+            uint64_t count = bvh_node_count(items.size());
+            uint64_t base = f.nodes.size();
+            if (base + count >= (1ull << 28)) return fail(RT_E_TOO_LARGE, "bvh: more than 2^28 nodes");
+            f.nodes.resize(base + count);
+            build_bvh(items, 0, items.size(), f.nodes.data() + base, base, 0, 0);
+            ref = make_ref(RT_REF_NODE, (uint32_t)base);
+            break;
+        }
+        case RT_OBJ_TRANSLATE: case RT_OBJ_ROTATE_Y: {
+            DXform x{};
+            x.parent = ctx;
+            x.depth = (ctx == 0 ? 0 : f.xforms[(size_t)ctx - 1].depth) + 1;
+            if (x.depth > XFORM_DEPTH_MAX) return fail(RT_E_TOO_LARGE, "transform nesting deeper than 8 levels");
+            if (o.kind == RT_OBJ_TRANSLATE) { x.kind = 0; x.a[0] = o.param[0]; x.a[1] = o.param[1]; x.a[2] = o.param[2]; }
+            else {
+                double radians = o.param[0] * (PI / 180.0); // hittable.rs:106
+                x.kind = 1; x.a[0] = std::sin(radians); x.a[1] = std::cos(radians); x.a[2] = 0.0;
+            }
+            size_t xi = f.xforms.size();
+            f.xforms.push_back(x);
+            uint32_t child;
+            int rc = flatten_object(o.a, (int32_t)xi + 1, child);
+            if (rc) return rc;
+            f.xforms[xi].child = child;
+            ref = make_ref(RT_REF_XFORM, (uint32_t)xi);
+            break;
+        }
+        case RT_OBJ_CONSTANT_MEDIUM: {
+            uint32_t boundary;
+            int rc = flatten_object(o.a, ctx, boundary);
+            if (rc) return rc;
+            DMedium m{};
+            m.boundary = boundary; m.mat = o.mat; m.neg_inv_density = -1.0 / o.param[0]; // constant_medium.rs:29
+            m.object = id;
+            ref = make_ref(RT_REF_MEDIUM, (uint32_t)f.media.size());
+            f.media.push_back(m);
+            f.has_medium = true;
+            break;
+        }
+        default: return fail(RT_E_INVALID, "object: unknown kind");
+        }
+        memo[key] = ref;
+        out = ref;
+        return RT_OK;
+    }
+
+    // Stack entries a traversal starting at `ref` can need.
+    int32_t need(uint32_t ref) {
+        uint32_t kind = RT_REF_KIND(ref), idx = RT_REF_INDEX(ref);
+        switch (kind) {
+        case RT_REF_NODE: {
+            if (need_node[idx] >= 0) return need_node[idx];
+            const DNode& n = f.nodes[idx];
+            int32_t l = need(n.left);
+            int32_t r;
+            if (n.left == n.right && !(n.flags & 1u)) r = l; // the duplicate child is not pushed
+            else r = std::max(1 + l, need(n.right));
+            need_node[idx] = r;
+            return r;
+        }
+        case RT_REF_LIST: {
+            const DList& l = f.lists[idx];
+            int32_t m = 0;
+            // very long primitive-only lists (ObjModel) need no per-item recursion
+            for (uint32_t k = 0; k < l.count; ++k) {
+                uint32_t r = f.list_items[l.first + k];
+                uint32_t rk = RT_REF_KIND(r);
+                if (rk == RT_REF_SPHERE || rk == RT_REF_QUAD || rk == RT_REF_TRI) continue;
+                m = std::max(m, need(r));
+            }
+            return 2 + m;
+        }
+        case RT_REF_XFORM: return 1 + need(f.xforms[idx].child);
+        case RT_REF_MEDIUM: return need(f.media[idx].boundary);
+        default: return 0;
+        }
+    }
+
+    int run() {
+        int rc;
+        if (!d) return fail(RT_E_INVALID, "null scene description");
+        if (d->n_spheres >= (1ull << 28) || d->n_quads >= (1ull << 28) || d->n_triangles >= (1ull << 28) || d->n_objects >= (1ull << 28))
+            return fail(RT_E_TOO_LARGE, "more than 2^28 primitives or objects");
+        if ((rc = check_textures())) return rc;
+        if ((rc = check_materials())) return rc;
+        f.images.assign(d->images, d->images + d->n_images);
+        f.image_bytes.assign(d->image_bytes, d->image_bytes + d->n_image_bytes);
+        f.perlins.assign(d->perlins, d->perlins + d->n_perlins);
+        if ((rc = build_primitives())) return rc;
+        if ((rc = compute_bounds())) return rc;
+        if (d->world < 0 || (uint64_t)d->world >= d->n_objects) return fail(RT_E_INVALID, "world: object id out of range");
+        if ((rc = flatten_object(d->world, 0, f.world))) return rc;
+        f.world_bounds = f.object_bounds[d->world];
+        // lights (camera.rs:81; hittable_list.rs:67-81, quad.rs:117-136, sphere.rs:117-141)
+        if (d->lights >= 0) {
+            if ((uint64_t)d->lights >= d->n_objects) return fail(RT_E_INVALID, "lights: object id out of range");
+            auto light_of = [&](int32_t id) -> DLight {
+                const rt_object& o = d->objects[id];
+                if (o.kind == RT_OBJ_SPHERE) return DLight{RT_REF_SPHERE, (uint32_t)o.a};
+                if (o.kind == RT_OBJ_QUAD) return DLight{RT_REF_QUAD, (uint32_t)o.a};
+                return DLight{REF_OTHER, 0u}; // trait defaults: pdf_value 0, random (1,0,0)
+            };
+            const rt_object& lo = d->objects[d->lights];
+            if (lo.kind == RT_OBJ_LIST) {
+                f.lights_is_list = 1;
+                for (int32_t k = 0; k < lo.b; ++k) {
+                    uint64_t idx = (uint64_t)lo.a + (uint64_t)k;
+                    if (lo.child_kind == RT_CHILD_OBJECTS) f.lights.push_back(light_of(d->children[idx]));
+                    else if (lo.child_kind == RT_CHILD_SPHERES) f.lights.push_back(DLight{RT_REF_SPHERE, (uint32_t)idx});
+                    else if (lo.child_kind == RT_CHILD_QUADS) f.lights.push_back(DLight{RT_REF_QUAD, (uint32_t)idx});
+                    else f.lights.push_back(DLight{REF_OTHER, 0u});
+                }
+                if (f.lights.empty())
+                    return fail(RT_E_INVALID, "lights: empty list (the reference panics in random_int(0,-1), hittable_list.rs:79)");
+            } else {
+                f.lights_is_list = 0;
+                f.lights.push_back(light_of(d->lights));
+            }
+            f.n_lights = (int32_t)f.lights.size();
+        } else {
+            f.n_lights = -1;
+        }
+        need_node.assign(f.nodes.size(), -1);
+        f.max_stack = (uint32_t)need(f.world) + 1;
+        if (f.max_stack > (uint32_t)STACK_MAX) return fail(RT_E_TOO_LARGE, "scene needs a deeper traversal stack than the kernels carry (32 entries)");
+        return RT_OK;
+    }
+};
+
+} // namespace
+
+int flatten_scene(const rt_scene_desc* desc, FlatScene& out, std::string& err) {
+    Flattener fl(desc, out, err);
+    return fl.run();
+}
+
+int camera_initialize(const rt_camera* c, rt_camera_derived* d, std::string& err) { // camera.rs:161-205
+    if (!c || !d) { err = "null camera"; return RT_E_INVALID; }
+    if (c->image_width < 1 || c->samples_per_pixel < 1) { err = "camera: image_width and samples_per_pixel must be >= 1"; return RT_E_INVALID; }
+    double hgt = (double)c->image_width / c->aspect_ratio;
+    int32_t image_height = (hgt != hgt) ? 0 : (hgt >= 2147483647.0 ? INT32_MAX : (hgt <= -2147483648.0 ? INT32_MIN : (int32_t)hgt));
+    d->image_height = image_height < 1 ? 1 : image_height;
+    d->sqrt_spp = (int32_t)std::sqrt((double)c->samples_per_pixel);
+    d->pixel_samples_scale = 1.0 / (double)(d->sqrt_spp * d->sqrt_spp);
+    d->recip_sqrt_spp = 1.0 / (double)d->sqrt_spp;
+    V3 lookfrom = v3(c->lookfrom), lookat = v3(c->lookat), vup = v3(c->vup);
+    V3 center = lookfrom;
+    double theta = c->vfov * PI / 180.0; // rtweekend.rs:11-13
+    double h = std::tan(theta / 2.0);
+    double viewport_height = 2.0 * h * c->focus_dist;
+    double viewport_width = viewport_height * ((double)c->image_width / (double)d->image_height);
+    V3 w = unit3(sub(lookfrom, lookat));
+    V3 u = unit3(cross3(vup, w));
+    V3 v = cross3(w, u);
+    V3 viewport_u = scale(viewport_width, u);
+    V3 viewport_v = scale(-viewport_height, v);
+    V3 pdu = divs(viewport_u, (double)c->image_width);
+    V3 pdv = divs(viewport_v, (double)d->image_height);
+    V3 upper_left = sub(sub(sub(center, scale(c->focus_dist, w)), divs(viewport_u, 2.0)), divs(viewport_v, 2.0));
+    V3 pixel00 = add(upper_left, scale(0.5, add(pdu, pdv)));
+    double defocus_radius = c->focus_dist * std::tan((c->defocus_angle / 2.0) * PI / 180.0);
+    put(d->center, center); put(d->pixel00_loc, pixel00); put(d->pixel_delta_u, pdu); put(d->pixel_delta_v, pdv);
+    put(d->defocus_disk_u, scale(defocus_radius, u)); put(d->defocus_disk_v, scale(defocus_radius, v));
+    return RT_OK;
+}
+
+} // namespace rt

@@ -1,0 +1,47 @@
+// flatten.h -- host flattener: object graph of the scene description -> linear arrays.
+#ifndef RT_FLATTEN_H
+#define RT_FLATTEN_H
+
+#include <string>
+#include <vector>
+#include "device_types.h"
+
+namespace rt {
+
+struct Box { // aabb.rs:10-14 as xmin xmax ymin ymax zmin zmax
+    double b[6];
+};
+
+struct FlatScene {
+    std::vector<DNode> nodes;
+    std::vector<DSphere> spheres;
+    std::vector<DQuad> quads;
+    std::vector<DTri> tris;
+    std::vector<DTriAux> tri_aux;
+    std::vector<DList> lists;
+    std::vector<uint32_t> list_items;
+    std::vector<DXform> xforms;
+    std::vector<DMedium> media;
+    std::vector<DMaterial> materials;
+    std::vector<DTexture> textures;
+    std::vector<rt_image> images;
+    std::vector<uint8_t> image_bytes;
+    std::vector<rt_perlin> perlins;
+    std::vector<DLight> lights;
+    std::vector<Box> object_bounds; // bounding_box() of every object of the description
+    uint32_t world = RT_REF_NONE;
+    int32_t n_lights = -1;
+    int32_t lights_is_list = 0;
+    uint32_t max_stack = 0;
+    bool has_medium = false;
+    Box world_bounds;
+};
+
+// Returns RT_OK or a negative RT_E_* code with `err` set.
+int flatten_scene(const rt_scene_desc* desc, FlatScene& out, std::string& err);
+
+// Camera::initialize (camera.rs:161-205).
+int camera_initialize(const rt_camera* cam, rt_camera_derived* out, std::string& err);
+
+} // namespace rt
+#endif

@@ -1,0 +1,736 @@
+// mi355rt.hip -- HIP kernels (gfx950) and the C ABI of libmi355rt.so.
+//
+// Kernels
+//   closest_hit_kernel  batched world.hit (camera.rs:258 / hittable.rs:49): persistent waves fetch
+//                       64-ray chunks from a global counter, one ray per lane, LDS stack.
+//   raygen_kernel       Camera::get_ray (camera.rs:207-240) for every (pixel, stratum) of a batch.
+//   extend_kernel       closest hit for the live paths of the current bounce (queue of path ids).
+//   shade_kernel        one bounce of Camera::ray_color (camera.rs:243-339) + wave-level
+//                       ballot compaction of the surviving paths into the next queue.
+//   accumulate_kernel   pixel_color += ray_color(...) in stratum order (camera.rs:110-131).
+// The product path has no CPU fallback: every entry point that computes needs a HIP device.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "flatten.h"
+#include "shade.h"
+
+using namespace rt;
+
+// ============================================================================ device code
+namespace {
+
+enum { C_WORK = 0, C_LIVE_IN = 1, C_LIVE_OUT = 2, C_NODES = 4, C_PRIMS = 5, C_RAYS = 6, C_WORDS = 16 };
+
+struct CamD { // Camera after initialize() (camera.rs:30-42)
+    rt_camera_derived d;
+    double defocus_angle;
+    double background[3];
+    int32_t image_width;
+    int32_t _pad;
+};
+
+struct PathState { // structure-of-arrays over path slots, all in HBM
+    double *ox, *oy, *oz, *dx, *dy, *dz, *time; // current ray
+    double *bx, *by, *bz;                        // throughput
+    double *lx, *ly, *lz;                        // accumulated radiance
+    double* hit_t;
+    uint32_t* hit_ref;
+    int32_t* hit_ctx;
+    uint32_t* rng_index;
+    uint32_t* queue[2];
+    unsigned long long* counters;
+};
+
+struct BatchGeom { // which (pixel, stratum) a path slot stands for
+    int32_t x0, y0, tw, th;        // tile origin and size
+    int32_t sample0, nsamples;     // strata [sample0, sample0 + nsamples)
+    uint32_t npix;                 // tw * th
+    uint32_t npaths;               // npix * nsamples
+};
+
+__device__ __forceinline__ unsigned long long wave_fetch(unsigned long long* counter, unsigned long long amount) {
+    unsigned long long base = 0;
+    if ((threadIdx.x & 63u) == 0u) base = atomicAdd(counter, amount);
+    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)base);
+    uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(BLOCK) void closest_hit_kernel(DScene S, rt_ray_batch rays, unsigned long long n, rt_hit_batch hits,
+                                                            unsigned long long seed, unsigned long long* counters) {
+    __shared__ uint32_t s_stack[STACK_MAX * BLOCK];
+    uint32_t* stk = s_stack + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t nn = 0, np = 0;
+    for (;;) {
+        unsigned long long base = wave_fetch(&counters[C_WORK], 64ull);
+        if (base >= n) break;
+        unsigned long long i = base + lane;
+        if (i < n) {
+            WorldRay w{rays.ox, rays.oy, rays.oz, rays.dx, rays.dy, rays.dz, i};
+            RayD r;
+            ray_in_context(S, w, 0, r);
+            double time = rays.time ? rays.time[i] : 0.0;
+            double tmin = rays.tmin ? rays.tmin[i] : 0.001;
+            Best b;
+            b.t = rays.tmax ? rays.tmax[i] : D_INF;
+            b.ref = RT_REF_NONE; b.ctx = 0;
+            Rng g{seed, 2u, (uint32_t)i, (uint32_t)(i >> 32), 0u};
+            traverse<true, COUNT>(S, S.world, r, 0, w, time, tmin, b, stk, 0, &g, nn, np);
+            if (b.ref != RT_REF_NONE) {
+                HitRec h;
+                finalize(S, w, time, b, h);
+                hits.t[i] = h.t;
+                hits.prim[i] = h.prim;
+                if (hits.u) hits.u[i] = h.u;
+                if (hits.v) hits.v[i] = h.v;
+                if (hits.front_face) hits.front_face[i] = h.front_face ? 1 : 0;
+                if (hits.mat) hits.mat[i] = h.mat;
+                if (hits.nx) hits.nx[i] = h.normal.x;
+                if (hits.ny) hits.ny[i] = h.normal.y;
+                if (hits.nz) hits.nz[i] = h.normal.z;
+                if (hits.px) hits.px[i] = h.p.x;
+                if (hits.py) hits.py[i] = h.p.y;
+                if (hits.pz) hits.pz[i] = h.p.z;
+            } else {
+                hits.t[i] = D_INF;
+                hits.prim[i] = RT_REF_NONE;
+                if (hits.u) hits.u[i] = 0.0;
+                if (hits.v) hits.v[i] = 0.0;
+                if (hits.front_face) hits.front_face[i] = 0;
+                if (hits.mat) hits.mat[i] = -1;
+                if (hits.nx) hits.nx[i] = 0.0;
+                if (hits.ny) hits.ny[i] = 0.0;
+                if (hits.nz) hits.nz[i] = 0.0;
+                if (hits.px) hits.px[i] = 0.0;
+                if (hits.py) hits.py[i] = 0.0;
+                if (hits.pz) hits.pz[i] = 0.0;
+            }
+        }
+    }
+    if (COUNT) {
+        atomicAdd(&counters[C_NODES], (unsigned long long)nn);
+        atomicAdd(&counters[C_PRIMS], (unsigned long long)np);
+    }
+}
+
+__global__ void init_batch_kernel(unsigned long long* counters, unsigned long long npaths) {
+    counters[C_WORK] = 0ull;
+    counters[C_LIVE_IN] = npaths;
+    counters[C_LIVE_OUT] = 0ull;
+}
+
+// After a bounce: the compacted queue becomes the input of the next one.
+__global__ void advance_kernel(unsigned long long* counters) {
+    counters[C_RAYS] += counters[C_LIVE_IN];
+    counters[C_LIVE_IN] = counters[C_LIVE_OUT];
+    counters[C_LIVE_OUT] = 0ull;
+    counters[C_WORK] = 0ull;
+}
+
+__global__ void reset_work_kernel(unsigned long long* counters) { counters[C_WORK] = 0ull; }
+
+__global__ __launch_bounds__(BLOCK) void raygen_kernel(CamD cam, BatchGeom bg, PathState ps, unsigned long long seed) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= bg.npaths) return;
+    uint32_t s_local = p / bg.npix, pix = p - s_local * bg.npix;
+    int32_t i = bg.x0 + (int32_t)(pix % (uint32_t)bg.tw);
+    int32_t j = bg.y0 + (int32_t)(pix / (uint32_t)bg.tw);
+    int32_t sidx = bg.sample0 + (int32_t)s_local;
+    int32_t s_j = sidx / cam.d.sqrt_spp, s_i = sidx % cam.d.sqrt_spp;
+    Rng g{seed, 0u, (uint32_t)(j * cam.image_width + i), (uint32_t)sidx, 0u};
+    // sample_square_stratified (camera.rs:227-231)
+    double px = (((double)s_i + g.next()) * cam.d.recip_sqrt_spp) - 0.5;
+    double py = (((double)s_j + g.next()) * cam.d.recip_sqrt_spp) - 0.5;
+    D3 pixel_sample = d3p(cam.d.pixel00_loc) + (((double)i + px) * d3p(cam.d.pixel_delta_u)) + (((double)j + py) * d3p(cam.d.pixel_delta_v));
+    D3 origin;
+    if (cam.defocus_angle <= 0.0) origin = d3p(cam.d.center);
+    else { // defocus_disk_sample (camera.rs:237-240)
+        D3 dsk = random_in_unit_disk(g);
+        origin = d3p(cam.d.center) + (dsk.x * d3p(cam.d.defocus_disk_u)) + (dsk.y * d3p(cam.d.defocus_disk_v));
+    }
+    D3 dir = pixel_sample - origin;
+    double time = g.next();
+    ps.ox[p] = origin.x; ps.oy[p] = origin.y; ps.oz[p] = origin.z;
+    ps.dx[p] = dir.x; ps.dy[p] = dir.y; ps.dz[p] = dir.z;
+    ps.time[p] = time;
+    ps.bx[p] = 1.0; ps.by[p] = 1.0; ps.bz[p] = 1.0;
+    ps.lx[p] = 0.0; ps.ly[p] = 0.0; ps.lz[p] = 0.0;
+    ps.rng_index[p] = g.index;
+    ps.queue[0][p] = p;
+}
+
+__global__ __launch_bounds__(BLOCK) void extend_kernel(DScene S, PathState ps, int qsel, unsigned long long seed, BatchGeom bg, int32_t image_width) {
+    __shared__ uint32_t s_stack[STACK_MAX * BLOCK];
+    uint32_t* stk = s_stack + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long n = ps.counters[C_LIVE_IN];
+    const uint32_t* queue = ps.queue[qsel];
+    uint32_t nn = 0, np = 0;
+    for (;;) {
+        unsigned long long base = wave_fetch(&ps.counters[C_WORK], 64ull);
+        if (base >= n) break;
+        unsigned long long q = base + lane;
+        if (q < n) {
+            uint32_t p = queue[q];
+            WorldRay w{ps.ox, ps.oy, ps.oz, ps.dx, ps.dy, ps.dz, p};
+            RayD r;
+            ray_in_context(S, w, 0, r);
+            double time = ps.time[p];
+            Best b;
+            b.t = D_INF; b.ref = RT_REF_NONE; b.ctx = 0;
+            uint32_t s_local = p / bg.npix, pix = p - s_local * bg.npix;
+            int32_t i = bg.x0 + (int32_t)(pix % (uint32_t)bg.tw);
+            int32_t j = bg.y0 + (int32_t)(pix / (uint32_t)bg.tw);
+            Rng g{seed, 0u, (uint32_t)(j * image_width + i), (uint32_t)(bg.sample0 + (int32_t)s_local), ps.rng_index[p]};
+            traverse<true, false>(S, S.world, r, 0, w, time, 0.001, b, stk, 0, &g, nn, np); // Interval::new(0.001, INFINITY) (camera.rs:258)
+            ps.hit_t[p] = b.t;
+            ps.hit_ref[p] = b.ref;
+            ps.hit_ctx[p] = b.ctx;
+            ps.rng_index[p] = g.index;
+        }
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void shade_kernel(DScene S, CamD cam, PathState ps, int qsel, unsigned long long seed, BatchGeom bg, int last_bounce) {
+    const unsigned long long n = ps.counters[C_LIVE_IN];
+    const uint32_t* qin = ps.queue[qsel];
+    uint32_t* qout = ps.queue[qsel ^ 1];
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    // every lane of a wave runs the same number of iterations so the ballot below stays convergent
+    const unsigned long long rounds = (n + stride - 1) / stride;
+    unsigned long long q = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (unsigned long long it = 0; it < rounds; ++it, q += stride) {
+        bool alive = false;
+        uint32_t p = 0;
+        if (q < n) {
+            p = qin[q];
+            D3 beta = d3(ps.bx[p], ps.by[p], ps.bz[p]);
+            D3 L = d3(ps.lx[p], ps.ly[p], ps.lz[p]);
+            Best b;
+            b.t = ps.hit_t[p]; b.ref = ps.hit_ref[p]; b.ctx = ps.hit_ctx[p];
+            if (b.ref == RT_REF_NONE) { // camera.rs:258-260
+                L = L + beta * d3p(cam.background);
+            } else {
+                WorldRay w{ps.ox, ps.oy, ps.oz, ps.dx, ps.dy, ps.dz, p};
+                double time = ps.time[p];
+                HitRec h;
+                finalize(S, w, time, b, h);
+                uint32_t s_local = p / bg.npix, pix = p - s_local * bg.npix;
+                int32_t i = bg.x0 + (int32_t)(pix % (uint32_t)bg.tw);
+                int32_t j = bg.y0 + (int32_t)(pix / (uint32_t)bg.tw);
+                Rng g{seed, 0u, (uint32_t)(j * cam.image_width + i), (uint32_t)(bg.sample0 + (int32_t)s_local), ps.rng_index[p]};
+                D3 ray_dir = d3(ps.dx[p], ps.dy[p], ps.dz[p]);
+                D3 no, nd;
+                alive = shade_hit(S, h, ray_dir, g, beta, L, no, nd);
+                if (alive) {
+                    if (last_bounce) { // the next ray_color call has depth 0 and returns black (camera.rs:252-254)
+                        L = L + beta * d3(0.0, 0.0, 0.0);
+                        alive = false;
+                    } else {
+                        ps.ox[p] = no.x; ps.oy[p] = no.y; ps.oz[p] = no.z;
+                        ps.dx[p] = nd.x; ps.dy[p] = nd.y; ps.dz[p] = nd.z;
+                        ps.bx[p] = beta.x; ps.by[p] = beta.y; ps.bz[p] = beta.z;
+                        ps.rng_index[p] = g.index;
+                    }
+                }
+            }
+            ps.lx[p] = L.x; ps.ly[p] = L.y; ps.lz[p] = L.z;
+        }
+        // compact: surviving paths of this wave take consecutive slots of the next queue
+        unsigned long long mask = __ballot(alive);
+        if (mask) {
+            int leader = __ffsll((long long)mask) - 1;
+            unsigned long long base = 0;
+            if ((int)lane == leader) base = atomicAdd(&ps.counters[C_LIVE_OUT], (unsigned long long)__popcll(mask));
+            uint32_t base_lo = (uint32_t)__shfl((int)(uint32_t)base, leader);
+            if (alive) qout[base_lo + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = p;
+        }
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void accumulate_kernel(PathState ps, BatchGeom bg, double* accum, int32_t image_width) {
+    uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= bg.npix) return;
+    int32_t i = bg.x0 + (int32_t)(pix % (uint32_t)bg.tw);
+    int32_t j = bg.y0 + (int32_t)(pix / (uint32_t)bg.tw);
+    double* a = accum + ((size_t)j * (size_t)image_width + (size_t)i) * 3;
+    double r = a[0], g = a[1], b = a[2];
+    for (int32_t s = 0; s < bg.nsamples; ++s) { // pixel_color += ray_color(...) in stratum order
+        size_t p = (size_t)s * bg.npix + pix;
+        r += ps.lx[p]; g += ps.ly[p]; b += ps.lz[p];
+    }
+    a[0] = r; a[1] = g; a[2] = b;
+}
+
+} // namespace
+
+// ============================================================================ host code
+struct rt_scene {
+    FlatScene flat;
+    DScene dev{};
+    bool host_only = false;
+    int device = -1;
+    std::vector<void*> allocs;
+    uint64_t device_bytes = 0;
+    unsigned long long* d_counters = nullptr;
+    unsigned long long* h_counters = nullptr; // pinned
+    hipEvent_t ev_hit0 = nullptr, ev_hit1 = nullptr, ev_r0 = nullptr, ev_r1 = nullptr;
+    bool hit_timed = false, render_timed = false;
+    rt_counters counters{};
+    int grid_blocks = 0;
+    // render workspace
+    PathState ps{};
+    uint64_t ws_paths = 0;
+    std::vector<void*> ws_allocs;
+};
+
+namespace {
+
+thread_local std::string g_err;
+
+int set_err(int code, const std::string& m) { g_err = m; return code; }
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return set_err(RT_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));           \
+    } while (0)
+
+template <class T>
+int upload(rt_scene* s, const std::vector<T>& v, const T** out) {
+    *out = nullptr;
+    size_t bytes = std::max<size_t>(v.size() * sizeof(T), 256); // never a null pointer in the kernels
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, bytes));
+    s->allocs.push_back(p);
+    s->device_bytes += bytes;
+    if (!v.empty()) HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = static_cast<const T*>(p);
+    return RT_OK;
+}
+
+int pick_grid(rt_scene* s) {
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, s->device));
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, closest_hit_kernel<false>, BLOCK, 0));
+    int per_cu2 = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, extend_kernel, BLOCK, 0));
+    per_cu = std::max(1, std::min(per_cu, per_cu2));
+    s->grid_blocks = prop.multiProcessorCount * per_cu;
+    return RT_OK;
+}
+
+void fill_host_dscene(rt_scene* s) {
+    FlatScene& f = s->flat;
+    DScene& d = s->dev;
+    d.nodes = f.nodes.data(); d.spheres = f.spheres.data(); d.quads = f.quads.data(); d.tris = f.tris.data();
+    d.tri_aux = f.tri_aux.data(); d.lists = f.lists.data(); d.list_items = f.list_items.data(); d.xforms = f.xforms.data();
+    d.media = f.media.data(); d.materials = f.materials.data(); d.textures = f.textures.data(); d.images = f.images.data();
+    d.image_bytes = f.image_bytes.data(); d.perlins = f.perlins.data(); d.lights = f.lights.data();
+    d.world = f.world; d.n_lights = f.n_lights; d.lights_is_list = f.lights_is_list; d._pad = 0;
+}
+
+int upload_scene(rt_scene* s) {
+    FlatScene& f = s->flat;
+    DScene& d = s->dev;
+    int rc;
+    if ((rc = upload(s, f.nodes, &d.nodes))) return rc;
+    if ((rc = upload(s, f.spheres, &d.spheres))) return rc;
+    if ((rc = upload(s, f.quads, &d.quads))) return rc;
+    if ((rc = upload(s, f.tris, &d.tris))) return rc;
+    if ((rc = upload(s, f.tri_aux, &d.tri_aux))) return rc;
+    if ((rc = upload(s, f.lists, &d.lists))) return rc;
+    if ((rc = upload(s, f.list_items, &d.list_items))) return rc;
+    if ((rc = upload(s, f.xforms, &d.xforms))) return rc;
+    if ((rc = upload(s, f.media, &d.media))) return rc;
+    if ((rc = upload(s, f.materials, &d.materials))) return rc;
+    if ((rc = upload(s, f.textures, &d.textures))) return rc;
+    if ((rc = upload(s, f.images, &d.images))) return rc;
+    if ((rc = upload(s, f.image_bytes, &d.image_bytes))) return rc;
+    if ((rc = upload(s, f.perlins, &d.perlins))) return rc;
+    if ((rc = upload(s, f.lights, &d.lights))) return rc;
+    d.world = f.world; d.n_lights = f.n_lights; d.lights_is_list = f.lights_is_list; d._pad = 0;
+    void* c = nullptr;
+    HIP_TRY(hipMalloc(&c, C_WORDS * sizeof(unsigned long long)));
+    s->allocs.push_back(c);
+    s->d_counters = static_cast<unsigned long long*>(c);
+    HIP_TRY(hipMemset(c, 0, C_WORDS * sizeof(unsigned long long)));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_counters), C_WORDS * sizeof(unsigned long long)));
+    HIP_TRY(hipEventCreate(&s->ev_hit0));
+    HIP_TRY(hipEventCreate(&s->ev_hit1));
+    HIP_TRY(hipEventCreate(&s->ev_r0));
+    HIP_TRY(hipEventCreate(&s->ev_r1));
+    return pick_grid(s);
+}
+
+void free_workspace(rt_scene* s) {
+    for (void* p : s->ws_allocs) (void)hipFree(p);
+    s->ws_allocs.clear();
+    s->ws_paths = 0;
+}
+
+int ensure_workspace(rt_scene* s, uint64_t paths) {
+    if (s->ws_paths >= paths) return RT_OK;
+    free_workspace(s);
+    auto alloc = [&](void** out, size_t bytes) -> int {
+        HIP_TRY(hipMalloc(out, bytes));
+        s->ws_allocs.push_back(*out);
+        return RT_OK;
+    };
+    PathState& ps = s->ps;
+    double** dbl[] = {&ps.ox, &ps.oy, &ps.oz, &ps.dx, &ps.dy, &ps.dz, &ps.time, &ps.bx, &ps.by, &ps.bz, &ps.lx, &ps.ly, &ps.lz, &ps.hit_t};
+    int rc;
+    for (double** a : dbl)
+        if ((rc = alloc(reinterpret_cast<void**>(a), paths * sizeof(double)))) return rc;
+    if ((rc = alloc(reinterpret_cast<void**>(&ps.hit_ref), paths * sizeof(uint32_t)))) return rc;
+    if ((rc = alloc(reinterpret_cast<void**>(&ps.hit_ctx), paths * sizeof(int32_t)))) return rc;
+    if ((rc = alloc(reinterpret_cast<void**>(&ps.rng_index), paths * sizeof(uint32_t)))) return rc;
+    if ((rc = alloc(reinterpret_cast<void**>(&ps.queue[0]), paths * sizeof(uint32_t)))) return rc;
+    if ((rc = alloc(reinterpret_cast<void**>(&ps.queue[1]), paths * sizeof(uint32_t)))) return rc;
+    ps.counters = s->d_counters;
+    s->ws_paths = paths;
+    return RT_OK;
+}
+
+uint64_t max_paths_setting() {
+    const char* e = getenv("MI355RT_MAX_PATHS");
+    if (e) { long long v = atoll(e); if (v >= 1024) return (uint64_t)v; }
+    return 1ull << 22;
+}
+
+int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit_batch* hits, uint64_t seed, uint32_t flags, hipStream_t st) {
+    if (n == 0) return RT_OK;
+    HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(unsigned long long), st)); // C_WORK
+    uint64_t waves = (n + 63) / 64;
+    int blocks = (int)std::min<uint64_t>((uint64_t)s->grid_blocks, (waves + (BLOCK / 64) - 1) / (BLOCK / 64));
+    HIP_TRY(hipEventRecord(s->ev_hit0, st));
+    if (flags & RT_HIT_COUNTERS)
+        hipLaunchKernelGGL(closest_hit_kernel<true>, dim3(blocks), dim3(BLOCK), 0, st, s->dev, *rays, (unsigned long long)n, *hits, (unsigned long long)seed, s->d_counters);
+    else
+        hipLaunchKernelGGL(closest_hit_kernel<false>, dim3(blocks), dim3(BLOCK), 0, st, s->dev, *rays, (unsigned long long)n, *hits, (unsigned long long)seed, s->d_counters);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(s->ev_hit1, st));
+    s->hit_timed = true;
+    s->counters.rays += n;
+    return RT_OK;
+}
+
+int render_impl(rt_scene* s, const rt_camera* cam, uint64_t seed, const rt_work* work, double* d_accum, hipStream_t st) {
+    CamD cd{};
+    std::string err;
+    int rc = camera_initialize(cam, &cd.d, err);
+    if (rc) return set_err(rc, err);
+    if (cam->max_depth < 0) return set_err(RT_E_INVALID, "camera: negative max_depth");
+    cd.defocus_angle = cam->defocus_angle;
+    cd.background[0] = cam->background[0]; cd.background[1] = cam->background[1]; cd.background[2] = cam->background[2];
+    cd.image_width = cam->image_width;
+    rt_work w;
+    const int32_t nstrata = cd.d.sqrt_spp * cd.d.sqrt_spp;
+    if (work) w = *work;
+    else { w.x0 = 0; w.y0 = 0; w.x1 = cam->image_width; w.y1 = cd.d.image_height; w.sample_begin = 0; w.sample_end = nstrata; }
+    if (w.x0 < 0 || w.y0 < 0 || w.x1 > cam->image_width || w.y1 > cd.d.image_height || w.x0 > w.x1 || w.y0 > w.y1)
+        return set_err(RT_E_INVALID, "render: work rectangle outside the image");
+    if (w.sample_begin < 0 || w.sample_end > nstrata || w.sample_begin > w.sample_end)
+        return set_err(RT_E_INVALID, "render: sample range outside [0, sqrt_spp^2]");
+    const int32_t tw = w.x1 - w.x0;
+    if (tw == 0 || w.y0 == w.y1 || w.sample_begin == w.sample_end) return RT_OK;
+    const uint64_t cap = max_paths_setting();
+    if ((uint64_t)tw > cap) return set_err(RT_E_TOO_LARGE, "render: one image row exceeds the path workspace");
+    const int32_t rows_per_tile = (int32_t)std::min<uint64_t>((uint64_t)(w.y1 - w.y0), cap / (uint64_t)tw);
+    const uint64_t tile_pix_max = (uint64_t)rows_per_tile * (uint64_t)tw;
+    const int32_t samples_per_batch = (int32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)(w.sample_end - w.sample_begin), cap / tile_pix_max));
+    if ((rc = ensure_workspace(s, tile_pix_max * (uint64_t)samples_per_batch))) return rc;
+    PathState ps = s->ps;
+    HIP_TRY(hipEventRecord(s->ev_r0, st));
+    for (int32_t y = w.y0; y < w.y1; y += rows_per_tile) {
+        const int32_t th = std::min(rows_per_tile, w.y1 - y);
+        for (int32_t s0 = w.sample_begin; s0 < w.sample_end; s0 += samples_per_batch) {
+            BatchGeom bg;
+            bg.x0 = w.x0; bg.y0 = y; bg.tw = tw; bg.th = th;
+            bg.sample0 = s0; bg.nsamples = std::min(samples_per_batch, w.sample_end - s0);
+            bg.npix = (uint32_t)tw * (uint32_t)th;
+            bg.npaths = bg.npix * (uint32_t)bg.nsamples;
+            hipLaunchKernelGGL(init_batch_kernel, dim3(1), dim3(1), 0, st, s->d_counters, (unsigned long long)bg.npaths);
+            hipLaunchKernelGGL(raygen_kernel, dim3((bg.npaths + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, cd, bg, ps, (unsigned long long)seed);
+            s->counters.paths += bg.npaths;
+            int qsel = 0;
+            uint64_t live = bg.npaths;
+            for (int32_t bounce = 0; bounce < cam->max_depth && live > 0; ++bounce) {
+                uint64_t waves = (live + 63) / 64;
+                int blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)s->grid_blocks, (waves + (BLOCK / 64) - 1) / (BLOCK / 64)));
+                hipLaunchKernelGGL(extend_kernel, dim3(blocks), dim3(BLOCK), 0, st, s->dev, ps, qsel, (unsigned long long)seed, bg, cam->image_width);
+                hipLaunchKernelGGL(shade_kernel, dim3(blocks), dim3(BLOCK), 0, st, s->dev, cd, ps, qsel, (unsigned long long)seed, bg, bounce == cam->max_depth - 1 ? 1 : 0);
+                hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, st, s->d_counters);
+                s->counters.extend_launches += 1;
+                qsel ^= 1;
+                // `live` only sizes the next launches (the kernels read the exact count on the device);
+                // refresh it from the device every few bounces so dead batches stop early.
+                if ((bounce & 3) == 3 || bounce < 4) {
+                    HIP_TRY(hipMemcpyAsync(s->h_counters, s->d_counters, C_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+                    HIP_TRY(hipStreamSynchronize(st));
+                    live = s->h_counters[C_LIVE_IN];
+                }
+            }
+            hipLaunchKernelGGL(accumulate_kernel, dim3((bg.npix + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, ps, bg, d_accum, cam->image_width);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    HIP_TRY(hipEventRecord(s->ev_r1, st));
+    s->render_timed = true;
+    return RT_OK;
+}
+
+int need_device(rt_scene* s) {
+    if (!s) return set_err(RT_E_INVALID, "null scene");
+    if (s->host_only) return set_err(RT_E_HIP, "scene was created with RT_SCENE_HOST_ONLY: no device data, nothing can be traced");
+    HIP_TRY(hipSetDevice(s->device));
+    return RT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* rt_last_error(void) { return g_err.c_str(); }
+const char* rt_version(void) { return "mi355rt 0.1 (gfx950)"; }
+
+int rt_scene_create(const rt_scene_desc* desc, uint32_t flags, rt_scene** out) {
+    if (!out) return set_err(RT_E_INVALID, "rt_scene_create: null out pointer");
+    *out = nullptr;
+    rt_scene* s = new rt_scene();
+    std::string err;
+    int rc = flatten_scene(desc, s->flat, err);
+    if (rc) { delete s; return set_err(rc, err); }
+    if (flags & RT_SCENE_HOST_ONLY) {
+        s->host_only = true;
+        fill_host_dscene(s);
+    } else {
+        hipError_t e = hipGetDevice(&s->device);
+        if (e != hipSuccess) { delete s; return set_err(RT_E_HIP, std::string("no HIP device: ") + hipGetErrorString(e)); }
+        rc = upload_scene(s);
+        if (rc) { rt_scene_destroy(s); return rc; }
+    }
+    *out = s;
+    return RT_OK;
+}
+
+int rt_scene_destroy(rt_scene* s) {
+    if (!s) return RT_OK;
+    if (!s->host_only) {
+        (void)hipSetDevice(s->device);
+        free_workspace(s);
+        for (void* p : s->allocs) (void)hipFree(p);
+        if (s->h_counters) (void)hipHostFree(s->h_counters);
+        if (s->ev_hit0) (void)hipEventDestroy(s->ev_hit0);
+        if (s->ev_hit1) (void)hipEventDestroy(s->ev_hit1);
+        if (s->ev_r0) (void)hipEventDestroy(s->ev_r0);
+        if (s->ev_r1) (void)hipEventDestroy(s->ev_r1);
+    }
+    delete s;
+    return RT_OK;
+}
+
+int rt_scene_get_info(const rt_scene* s, rt_scene_info* info) {
+    if (!s || !info) return set_err(RT_E_INVALID, "rt_scene_get_info: null argument");
+    info->n_nodes = s->flat.nodes.size();
+    info->n_lists = s->flat.lists.size();
+    info->n_xforms = s->flat.xforms.size();
+    info->n_media = s->flat.media.size();
+    info->n_lights = s->flat.n_lights < 0 ? 0 : (uint64_t)s->flat.n_lights;
+    info->world_ref = s->flat.world;
+    info->max_stack = s->flat.max_stack;
+    info->device_bytes = s->device_bytes;
+    for (int k = 0; k < 6; ++k) info->world_bounds[k] = s->flat.world_bounds.b[k];
+    return RT_OK;
+}
+
+int rt_scene_get_nodes(const rt_scene* s, uint64_t first, uint64_t count, rt_bvh_node* out) {
+    if (!s || !out) return set_err(RT_E_INVALID, "rt_scene_get_nodes: null argument");
+    if (first + count > s->flat.nodes.size()) return set_err(RT_E_INVALID, "rt_scene_get_nodes: range outside the node array");
+    std::memcpy(out, s->flat.nodes.data() + first, count * sizeof(rt_bvh_node));
+    return RT_OK;
+}
+
+int rt_scene_object_bounds(const rt_scene* s, int32_t object, double out[6]) {
+    if (!s || !out) return set_err(RT_E_INVALID, "rt_scene_object_bounds: null argument");
+    if (object < 0 || (size_t)object >= s->flat.object_bounds.size()) return set_err(RT_E_INVALID, "rt_scene_object_bounds: object id out of range");
+    for (int k = 0; k < 6; ++k) out[k] = s->flat.object_bounds[object].b[k];
+    return RT_OK;
+}
+
+int rt_closest_hit_device(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit_batch* hits, uint64_t seed, uint32_t flags, void* hip_stream) {
+    int rc = need_device(s);
+    if (rc) return rc;
+    if (!rays || !hits) return set_err(RT_E_INVALID, "rt_closest_hit_device: null batch");
+    if (n && (!rays->ox || !rays->oy || !rays->oz || !rays->dx || !rays->dy || !rays->dz || !hits->t || !hits->prim))
+        return set_err(RT_E_INVALID, "rt_closest_hit_device: origin, direction, t and prim arrays are required");
+    return launch_closest_hit(s, rays, n, hits, seed, flags, static_cast<hipStream_t>(hip_stream));
+}
+
+int rt_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit_batch* hits, uint64_t seed, uint32_t flags) {
+    int rc = need_device(s);
+    if (rc) return rc;
+    if (!rays || !hits) return set_err(RT_E_INVALID, "rt_closest_hit: null batch");
+    if (n == 0) return RT_OK;
+    if (!rays->ox || !rays->oy || !rays->oz || !rays->dx || !rays->dy || !rays->dz || !hits->t || !hits->prim)
+        return set_err(RT_E_INVALID, "rt_closest_hit: origin, direction, t and prim arrays are required");
+    std::vector<void*> tmp;
+    auto cleanup = [&]() { for (void* p : tmp) (void)hipFree(p); };
+    auto to_dev = [&](const void* h, size_t bytes, const void** d) -> int {
+        *d = nullptr;
+        if (!h) return RT_OK;
+        void* p = nullptr;
+        HIP_TRY(hipMalloc(&p, bytes));
+        tmp.push_back(p);
+        HIP_TRY(hipMemcpy(p, h, bytes, hipMemcpyHostToDevice));
+        *d = p;
+        return RT_OK;
+    };
+    auto out_dev = [&](const void* h, size_t bytes, void** d) -> int {
+        *d = nullptr;
+        if (!h) return RT_OK;
+        HIP_TRY(hipMalloc(d, bytes));
+        tmp.push_back(*d);
+        return RT_OK;
+    };
+    rt_ray_batch dr{};
+    rt_hit_batch dh{};
+    const double* const src[9] = {rays->ox, rays->oy, rays->oz, rays->dx, rays->dy, rays->dz, rays->time, rays->tmin, rays->tmax};
+    const double** dst[9] = {&dr.ox, &dr.oy, &dr.oz, &dr.dx, &dr.dy, &dr.dz, &dr.time, &dr.tmin, &dr.tmax};
+    for (int k = 0; k < 9; ++k)
+        if ((rc = to_dev(src[k], n * sizeof(double), reinterpret_cast<const void**>(dst[k])))) { cleanup(); return rc; }
+    double* const hsrc[9] = {hits->t, hits->u, hits->v, hits->nx, hits->ny, hits->nz, hits->px, hits->py, hits->pz};
+    double** hdst[9] = {&dh.t, &dh.u, &dh.v, &dh.nx, &dh.ny, &dh.nz, &dh.px, &dh.py, &dh.pz};
+    for (int k = 0; k < 9; ++k)
+        if ((rc = out_dev(hsrc[k], n * sizeof(double), reinterpret_cast<void**>(hdst[k])))) { cleanup(); return rc; }
+    if ((rc = out_dev(hits->prim, n * sizeof(uint32_t), reinterpret_cast<void**>(&dh.prim)))) { cleanup(); return rc; }
+    if ((rc = out_dev(hits->front_face, n * sizeof(uint8_t), reinterpret_cast<void**>(&dh.front_face)))) { cleanup(); return rc; }
+    if ((rc = out_dev(hits->mat, n * sizeof(int32_t), reinterpret_cast<void**>(&dh.mat)))) { cleanup(); return rc; }
+    rc = launch_closest_hit(s, &dr, n, &dh, seed, flags, nullptr);
+    if (rc) { cleanup(); return rc; }
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) { cleanup(); return set_err(RT_E_HIP, std::string("closest_hit kernel: ") + hipGetErrorString(e)); }
+    auto back = [&](void* h, const void* d, size_t bytes) -> int {
+        if (!h) return RT_OK;
+        HIP_TRY(hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost));
+        return RT_OK;
+    };
+    for (int k = 0; k < 9; ++k)
+        if ((rc = back(hsrc[k], *hdst[k], n * sizeof(double)))) { cleanup(); return rc; }
+    if ((rc = back(hits->prim, dh.prim, n * sizeof(uint32_t)))) { cleanup(); return rc; }
+    if ((rc = back(hits->front_face, dh.front_face, n * sizeof(uint8_t)))) { cleanup(); return rc; }
+    if ((rc = back(hits->mat, dh.mat, n * sizeof(int32_t)))) { cleanup(); return rc; }
+    cleanup();
+    return RT_OK;
+}
+
+int rt_camera_initialize(const rt_camera* cam, rt_camera_derived* out) {
+    std::string err;
+    int rc = camera_initialize(cam, out, err);
+    return rc ? set_err(rc, err) : RT_OK;
+}
+
+int rt_render_device(rt_scene* s, const rt_camera* cam, uint64_t seed, const rt_work* work, double* accum, void* hip_stream) {
+    int rc = need_device(s);
+    if (rc) return rc;
+    if (!cam || !accum) return set_err(RT_E_INVALID, "rt_render_device: null argument");
+    return render_impl(s, cam, seed, work, accum, static_cast<hipStream_t>(hip_stream));
+}
+
+int rt_render(rt_scene* s, const rt_camera* cam, uint64_t seed, const rt_work* work, double* accum) {
+    int rc = need_device(s);
+    if (rc) return rc;
+    if (!cam || !accum) return set_err(RT_E_INVALID, "rt_render: null argument");
+    rt_camera_derived d;
+    std::string err;
+    if ((rc = camera_initialize(cam, &d, err))) return set_err(rc, err);
+    size_t bytes = (size_t)cam->image_width * (size_t)d.image_height * 3 * sizeof(double);
+    double* dacc = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dacc), bytes));
+    hipError_t e = hipMemcpy(dacc, accum, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        rc = render_impl(s, cam, seed, work, dacc, nullptr);
+        if (rc == RT_OK) {
+            e = hipDeviceSynchronize();
+            if (e == hipSuccess) e = hipMemcpy(accum, dacc, bytes, hipMemcpyDeviceToHost);
+        }
+    }
+    (void)hipFree(dacc);
+    if (rc) return rc;
+    if (e != hipSuccess) return set_err(RT_E_HIP, std::string("rt_render: ") + hipGetErrorString(e));
+    return RT_OK;
+}
+
+int rt_resolve_rgb8(const rt_camera* cam, const double* accum, uint8_t* rgb) { // camera.rs:133-135, color.rs:58-80
+    if (!cam || !accum || !rgb) return set_err(RT_E_INVALID, "rt_resolve_rgb8: null argument");
+    rt_camera_derived d;
+    std::string err;
+    int rc = camera_initialize(cam, &d, err);
+    if (rc) return set_err(rc, err);
+    size_t n = (size_t)cam->image_width * (size_t)d.image_height * 3;
+    for (size_t k = 0; k < n; ++k) {
+        double x = d.pixel_samples_scale * accum[k];
+        x = x > 0.0 ? std::sqrt(x) : 0.0;              // linear_to_gamma (NaN -> 0)
+        x = x < 0.000 ? 0.000 : (x > 0.999 ? 0.999 : x); // Interval::clamp
+        double b = 256.0 * x;
+        rgb[k] = (uint8_t)(int32_t)b;
+    }
+    return RT_OK;
+}
+
+int rt_write_ppm(const char* path, int32_t width, int32_t height, const uint8_t* rgb) { // camera.rs:86,151-154
+    if (!path || !rgb || width < 0 || height < 0) return set_err(RT_E_INVALID, "rt_write_ppm: bad argument");
+    FILE* fp = std::fopen(path, "w");
+    if (!fp) return set_err(RT_E_INVALID, std::string("rt_write_ppm: cannot open ") + path);
+    std::fprintf(fp, "P3\n%d %d\n255\n", width, height);
+    size_t n = (size_t)width * (size_t)height;
+    for (size_t p = 0; p < n; ++p) std::fprintf(fp, "%d %d %d\n", (int)rgb[3 * p], (int)rgb[3 * p + 1], (int)rgb[3 * p + 2]);
+    std::fclose(fp);
+    return RT_OK;
+}
+
+int rt_get_counters(rt_scene* s, rt_counters* out) {
+    if (!s || !out) return set_err(RT_E_INVALID, "rt_get_counters: null argument");
+    if (!s->host_only) {
+        HIP_TRY(hipSetDevice(s->device));
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(s->h_counters, s->d_counters, C_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        s->counters.node_visits = s->h_counters[C_NODES];
+        s->counters.prim_tests = s->h_counters[C_PRIMS];
+        if (s->hit_timed) { float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, s->ev_hit0, s->ev_hit1)); s->counters.ms_last_closest_hit = ms; }
+        if (s->render_timed) { float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, s->ev_r0, s->ev_r1)); s->counters.ms_last_render = ms; }
+        s->counters.render_rays = s->h_counters[C_RAYS];
+    }
+    *out = s->counters;
+    return RT_OK;
+}
+
+int rt_reset_counters(rt_scene* s) {
+    if (!s) return set_err(RT_E_INVALID, "rt_reset_counters: null scene");
+    s->counters = rt_counters{};
+    if (!s->host_only) {
+        HIP_TRY(hipSetDevice(s->device));
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemset(s->d_counters, 0, C_WORDS * sizeof(unsigned long long)));
+    }
+    return RT_OK;
+}
+
+double rt_rng_uniform(uint64_t seed, uint32_t stream, uint32_t a, uint32_t b, uint64_t index) {
+    return philox_uniform(seed, stream, a, b, index);
+}
+
+} // extern "C"

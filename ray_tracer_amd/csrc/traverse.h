@@ -1,0 +1,252 @@
+// traverse.h -- per-lane stack traversal of the flattened scene (closest hit) and
+// reconstruction of the full hit record.
+//
+// One ray per lane.  The traversal stack lives in LDS, laid out [entry][lane] so
+// the 64 lanes of a wave touch 64 consecutive banks.  The visit order is the
+// reference's: BvhNode::hit tests its box with the interval it is handed, then
+// left, then right with the interval shortened to the closest hit so far
+// (bvh.rs:118-140); HittableList::hit scans its members in order
+// (hittable_list.rs:45-61).  Because the interval every callee receives is always
+// [tmin, closest-so-far], an explicit stack with "push right, descend left"
+// reproduces the recursion exactly.
+//
+// During traversal only (t, primitive, transform context) of the closest hit are
+// kept; p, normal, front_face, u, v are recomputed afterwards by `finalize` with
+// the same arithmetic the reference's hit() used, which yields the same bits.
+#ifndef RT_TRAVERSE_H
+#define RT_TRAVERSE_H
+
+#include "device_math.h"
+
+namespace rt {
+
+constexpr int BLOCK = 256; // threads per workgroup of every traversal kernel
+
+// Where the world-space ray of this lane lives (SoA arrays + index): transforms
+// re-derive the context ray from it when a Translate/RotateY subtree is left.
+struct WorldRay {
+    const double* ox; const double* oy; const double* oz;
+    const double* dx; const double* dy; const double* dz;
+    uint64_t i;
+};
+
+struct Best {
+    double t;      // closest hit so far == upper end of the interval handed to every callee
+    uint32_t ref;  // primitive (or medium) that produced it, RT_REF_NONE if none
+    int32_t ctx;   // transform context it was found in
+};
+
+// Translate::hit / RotateY::hit ray transform (hittable.rs:80-81, 147-157).
+RT_DEV void apply_xform(const DXform& x, RayD& r) {
+    if (x.kind == 0) {
+        r.ox = r.ox - x.a[0]; r.oy = r.oy - x.a[1]; r.oz = r.oz - x.a[2];
+    } else {
+        double s = x.a[0], c = x.a[1];
+        double nox = c * r.ox - s * r.oz, noz = s * r.ox + c * r.oz;
+        double ndx = c * r.dx - s * r.dz, ndz = s * r.dx + c * r.dz;
+        r.ox = nox; r.oz = noz; r.dx = ndx; r.dz = ndz;
+    }
+}
+
+// Ray of this lane in context `ctx`: the world ray pushed through the chain of
+// transforms from the outermost to `ctx`, one rounding per reference operation.
+RT_DEV void ray_in_context(const DScene& S, const WorldRay& w, int32_t ctx, RayD& r) {
+    r.ox = w.ox[w.i]; r.oy = w.oy[w.i]; r.oz = w.oz[w.i];
+    r.dx = w.dx[w.i]; r.dy = w.dy[w.i]; r.dz = w.dz[w.i];
+    if (ctx != 0) {
+        int depth = S.xforms[ctx - 1].depth;
+        for (int level = 1; level <= depth; ++level) {
+            int32_t c = ctx;
+            for (int k = depth; k > level; --k) c = S.xforms[c - 1].parent;
+            apply_xform(S.xforms[c - 1], r);
+        }
+    }
+    set_inverse(r);
+}
+
+struct NodeLoad { double b[6]; uint32_t left, right, flags, pad; };
+RT_DEV void load_node(const DNode* nodes, uint32_t idx, NodeLoad& n) {
+    // 64-byte record, four 16-byte loads per lane
+    const double2* p = reinterpret_cast<const double2*>(nodes + idx);
+    double2 a = p[0], b = p[1], c = p[2];
+    const uint4 d = *reinterpret_cast<const uint4*>(p + 3);
+    n.b[0] = a.x; n.b[1] = a.y; n.b[2] = b.x; n.b[3] = b.y; n.b[4] = c.x; n.b[5] = c.y;
+    n.left = d.x; n.right = d.y; n.flags = d.z; n.pad = d.w;
+}
+
+// Closest hit of `root` for the lane's ray over (tmin, best.t].  TOP = the world query
+// (constant media allowed); the nested boundary queries of a medium run with TOP = false.
+// `stk` points at this lane's column of the LDS stack, entries are BLOCK words apart.
+template <bool TOP, bool COUNT>
+__device__ __forceinline__ void traverse(const DScene& S, uint32_t root, RayD ray, int32_t ctx, const WorldRay& w,
+                                         double time, double tmin, Best& best, uint32_t* stk, int sp0, Rng* rng,
+                                         uint32_t& n_nodes, uint32_t& n_prims) {
+    int sp = sp0;
+    uint32_t cur = root;
+    for (;;) {
+        const uint32_t kind = cur >> 28, idx = cur & 0x0FFFFFFFu;
+        bool pop = true;
+        if (kind == RT_REF_NODE) {
+            NodeLoad n;
+            load_node(S.nodes, idx, n);
+            if (COUNT) ++n_nodes;
+            if (slab_test(n.b, ray, tmin, best.t)) {
+                // A one-object span stores the object as both children (bvh.rs:41-44).  Testing it
+                // a second time cannot change the record unless it draws random numbers, so the
+                // duplicate is visited only when the subtree holds a constant medium.
+                if (n.right != n.left || (n.flags & 1u)) { stk[sp * BLOCK] = n.right; ++sp; }
+                cur = n.left;
+                pop = false;
+            }
+        } else if (kind == RT_REF_TRI) {
+            const DTri* tp = S.tris + idx;
+            if (COUNT) ++n_prims;
+            double t, u, v;
+            if (tri_test(d3p(tp->v0), d3p(tp->v1), d3p(tp->v2), ray, tmin, best.t, t, u, v)) { best.t = t; best.ref = cur; best.ctx = ctx; }
+        } else if (kind == RT_REF_SPHERE) {
+            const DSphere s = S.spheres[idx];
+            if (COUNT) ++n_prims;
+            double t;
+            if (sphere_test(s, ray, time, tmin, best.t, t)) { best.t = t; best.ref = cur; best.ctx = ctx; }
+        } else if (kind == RT_REF_QUAD) {
+            const DQuad* q = S.quads + idx;
+            if (COUNT) ++n_prims;
+            double t, al, be;
+            if (quad_test(*q, ray, tmin, best.t, t, al, be)) { best.t = t; best.ref = cur; best.ctx = ctx; }
+        } else if (kind == RT_REF_LIST || kind == REF_LISTCONT) {
+            uint32_t pos = 0;
+            if (kind == REF_LISTCONT) { --sp; pos = stk[sp * BLOCK]; }
+            const DList l = S.lists[idx];
+            if (pos < l.count) {
+                if (pos + 1 < l.count) {
+                    stk[sp * BLOCK] = pos + 1; ++sp;
+                    stk[sp * BLOCK] = make_ref(REF_LISTCONT, idx); ++sp;
+                }
+                cur = S.list_items[l.first + pos];
+                pop = false;
+            }
+        } else if (kind == RT_REF_XFORM) {
+            const DXform x = S.xforms[idx];
+            stk[sp * BLOCK] = make_ref(REF_POPX, (uint32_t)ctx); ++sp;
+            apply_xform(x, ray);
+            set_inverse(ray);
+            ctx = (int32_t)idx + 1;
+            cur = x.child;
+            pop = false;
+        } else if (kind == REF_POPX) {
+            ctx = (int32_t)idx;
+            ray_in_context(S, w, ctx, ray);
+        } else if (kind == RT_REF_MEDIUM) {
+            if constexpr (TOP) { // ConstantMedium::hit (constant_medium.rs:48-104)
+                const DMedium m = S.media[idx];
+                if (COUNT) ++n_prims;
+                double t1 = 0.0, t2 = 0.0;
+                bool ok = true;
+                for (int pass = 0; pass < 2 && ok; ++pass) {
+                    Best b; b.t = D_INF; b.ref = RT_REF_NONE; b.ctx = 0;
+                    double lo = pass == 0 ? -D_INF : t1 + 0.0001; // Interval::UNIVERSE, then [rec1.t + 0.0001, inf)
+                    traverse<false, COUNT>(S, m.boundary, ray, ctx, w, time, lo, b, stk, sp, nullptr, n_nodes, n_prims);
+                    if (b.ref == RT_REF_NONE) ok = false;
+                    else if (pass == 0) t1 = b.t; else t2 = b.t;
+                }
+                if (ok) {
+                    double rec1_t = t1 < tmin ? tmin : t1;
+                    double rec2_t = t2 > best.t ? best.t : t2;
+                    if (!(rec1_t >= rec2_t)) {
+                        if (rec1_t < 0.0) rec1_t = 0.0;
+                        double ray_length = length(d3(ray.dx, ray.dy, ray.dz));
+                        double distance_inside_boundary = (rec2_t - rec1_t) * ray_length;
+                        double hit_distance = m.neg_inv_density * log(rng->next());
+                        if (!(hit_distance > distance_inside_boundary)) {
+                            best.t = rec1_t + hit_distance / ray_length;
+                            best.ref = cur; best.ctx = ctx;
+                        }
+                    }
+                }
+            }
+        }
+        if (pop) {
+            if (sp == sp0) break;
+            --sp;
+            cur = stk[sp * BLOCK];
+        }
+    }
+}
+
+// Full HitRecord (hittable.rs:14-22) of the closest hit found by `traverse`.
+struct HitRec {
+    double t, u, v;
+    D3 p, normal;
+    int32_t mat;
+    uint32_t prim;  // reported primitive id: (kind << 28) | index in the scene description
+    bool front_face;
+};
+
+RT_DEV void set_face_normal(HitRec& h, D3 dir, D3 outward_normal) { // hittable.rs:25-33
+    h.front_face = dot(dir, outward_normal) < 0.0;
+    h.normal = h.front_face ? outward_normal : -outward_normal;
+}
+
+RT_DEV void finalize(const DScene& S, const WorldRay& w, double time, const Best& b, HitRec& h) {
+    RayD r;
+    ray_in_context(S, w, b.ctx, r);
+    const D3 o = d3(r.ox, r.oy, r.oz), d = d3(r.dx, r.dy, r.dz);
+    const uint32_t kind = b.ref >> 28, idx = b.ref & 0x0FFFFFFFu;
+    h.t = b.t;
+    h.p = o + b.t * d; // r.at(t) (ray.rs:54-56)
+    h.u = 0.0; h.v = 0.0;
+    h.prim = b.ref;
+    if (kind == RT_REF_SPHERE) { // sphere.rs:101-108
+        const DSphere s = S.spheres[idx];
+        D3 center = d3(s.c[0], s.c[1], s.c[2]) + time * d3(s.dc[0], s.dc[1], s.dc[2]);
+        D3 outward_normal = (h.p - center) / s.radius;
+        set_face_normal(h, d, outward_normal);
+        double theta = acos(-outward_normal.y); // sphere.rs:47-55
+        double phi = atan2(-outward_normal.z, outward_normal.x) + D_PI;
+        h.u = phi / (2.0 * D_PI);
+        h.v = theta / D_PI;
+        h.mat = s.mat;
+    } else if (kind == RT_REF_QUAD) { // quad.rs:95-108
+        const DQuad* q = S.quads + idx;
+        D3 hp = h.p - d3p(q->q);
+        h.u = dot(d3p(q->w), cross(hp, d3p(q->v)));
+        h.v = dot(d3p(q->w), cross(d3p(q->u), hp));
+        set_face_normal(h, d, d3p(q->n));
+        h.mat = q->mat;
+    } else if (kind == RT_REF_TRI) { // triangle.rs:155-196
+        const DTri* tp = S.tris + idx;
+        D3 v0 = d3p(tp->v0), v1 = d3p(tp->v1), v2 = d3p(tp->v2);
+        D3 edge1 = v1 - v0, edge2 = v2 - v0;
+        D3 hh = cross(d, edge2);
+        double f = 1.0 / dot(edge1, hh);
+        D3 s = o - v0;
+        h.u = f * dot(s, hh);
+        h.v = f * dot(d, cross(s, edge1));
+        const DTriAux ax = S.tri_aux[idx];
+        set_face_normal(h, d, d3(ax.n[0], ax.n[1], ax.n[2]));
+        h.mat = ax.mat;
+    } else { // constant medium (constant_medium.rs:96-101); u,v are not written by the reference
+        const DMedium m = S.media[idx];
+        h.normal = d3(1.0, 0.0, 0.0);
+        h.front_face = true;
+        h.mat = m.mat;
+        h.prim = make_ref(RT_REF_MEDIUM, (uint32_t)m.object);
+    }
+    // Unwind the transform chain innermost first: RotateY rotates p and normal back and keeps
+    // front_face (hittable.rs:165-179), Translate adds its offset to p (hittable.rs:86).
+    for (int32_t c = b.ctx; c != 0;) {
+        const DXform x = S.xforms[c - 1];
+        if (x.kind == 0) {
+            h.p = d3(h.p.x + x.a[0], h.p.y + x.a[1], h.p.z + x.a[2]);
+        } else {
+            double s = x.a[0], cs = x.a[1];
+            D3 p = d3(cs * h.p.x + s * h.p.z, h.p.y, -s * h.p.x + cs * h.p.z);
+            D3 n = d3(cs * h.normal.x + s * h.normal.z, h.normal.y, -s * h.normal.x + cs * h.normal.z);
+            h.p = p; h.normal = n;
+        }
+        c = x.parent;
+    }
+}
+
+} // namespace rt
+#endif

@@ -1,0 +1,164 @@
+"""GPU parity: rt_closest_hit (HIP kernels, through the C ABI) against the CPU oracle on
+identical seeded ray batches.  Bar: primitive id exact, t / p / normal bit-exact (the
+intersection arithmetic is +,-,*,/,sqrt with contraction off on both sides); sphere u,v go
+through acos/atan2, whose device and glibc implementations may differ in the last ulps,
+so they are held to 1e-12."""
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+import ray_tracer_amd as rt
+from ray_tracer_amd import _ffi as F
+from ray_tracer_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+EXACT = ("t", "prim", "front_face", "mat", "nx", "ny", "nz", "px", "py", "pz")
+
+
+def compare(desc, o, d, time=None, tmin=None, tmax=None, seed=0, min_hits=1, flags=0):
+    gpu = rt.Scene(desc)
+    cpu = O.OracleScene(desc)
+    a = gpu.closest_hit(o, d, time=time, tmin=tmin, tmax=tmax, seed=seed, flags=flags)
+    b = cpu.closest_hit(o, d, time=time, tmin=tmin, tmax=tmax, seed=seed)
+    nhit = int((b["prim"] != F.RT_REF_NONE).sum())
+    assert nhit >= min_hits, f"only {nhit} oracle hits: the batch does not exercise the scene"
+    for f in EXACT:
+        bad = np.nonzero(~((a[f] == b[f]) | ((a[f] != a[f]) & (b[f] != b[f]))))[0]
+        assert bad.size == 0, (f, bad[:5], a[f][bad[:5]], b[f][bad[:5]], [hex(int(x)) for x in b["prim"][bad[:5]]])
+    medium = (b["prim"] >> 28) == F.RT_REF_MEDIUM  # u,v of a medium hit are unspecified (stale in the reference)
+    for f in ("u", "v"):
+        assert np.allclose(a[f][~medium], b[f][~medium], rtol=0, atol=1e-12), f
+    gpu.close()
+    return a, b
+
+
+def rays_for(bounds, n, seed, spread=0.25):
+    b = np.array(bounds)
+    ext = np.array([b[1] - b[0], b[3] - b[2], b[5] - b[4]])
+    big = [b[0] - spread * ext[0], b[1] + spread * ext[0], b[2] - spread * ext[1], b[3] + spread * ext[1],
+           b[4] - spread * ext[2], b[5] + spread * ext[2]]
+    return scenes.incoherent_rays(n, big, seed=seed)
+
+
+def test_kat_vectors_on_gpu():
+    import json, os
+    kat = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kat.json")))
+    m = rt.Lambertian(rt.Color(.5, .5, .5))
+    r = kat["ray"]
+    o, d = np.array([r["o"]], float), np.array([r["d"]], float)
+    k = kat["sphere"]
+    h = rt.Scene(rt.HittableList.with_object(rt.Sphere(rt.Point3(*k["center"]), k["radius"], m))).closest_hit(o, d)
+    assert h["t"][0] == k["t"] and [h["nx"][0], h["ny"][0], h["nz"][0]] == k["normal"] and h["front_face"][0] == 1
+    assert abs(h["u"][0] - k["u"]) < 1e-15 and abs(h["v"][0] - k["v"]) < 1e-15
+    k = kat["quad"]
+    h = rt.Scene(rt.HittableList.with_object(rt.Quad(rt.Point3(*k["q"]), rt.Vec3(*k["u"]), rt.Vec3(*k["v"]), m))).closest_hit(o, d)
+    assert h["t"][0] == k["t"] and h["u"][0] == k["alpha"] and h["v"][0] == k["beta"] and h["nz"][0] == 1.0
+    k = kat["triangle"]
+    h = rt.Scene(rt.HittableList.with_object(rt.Triangle(rt.Point3(*k["v0"]), rt.Point3(*k["v1"]), rt.Point3(*k["v2"]), m))).closest_hit(o, d)
+    assert h["t"][0] == k["t"] and h["u"][0] == k["u"] and h["v"][0] == k["v"] and h["nz"][0] == 1.0
+
+
+def test_mixed_primitives_list_and_bvh():
+    g = np.random.default_rng(5)
+    m = [rt.Lambertian(rt.Color(.5, .5, .5)), rt.Metal(rt.Color(.8, .8, .8), 0.1), rt.Dielectric(1.5)]
+    lst = rt.HittableList()
+    for i in range(200):
+        c = g.uniform(-5, 5, 3)
+        if i % 4 == 0:
+            lst.add(rt.Sphere.new_moving(rt.Point3(*c), rt.Point3(*(c + g.uniform(-.5, .5, 3))), g.uniform(0.1, 0.6), m[i % 3]))
+        else:
+            lst.add(rt.Sphere(rt.Point3(*c), g.uniform(0.1, 0.6), m[i % 3]))
+    for i in range(80):
+        lst.add(rt.Quad(rt.Point3(*g.uniform(-5, 5, 3)), rt.Vec3(*g.uniform(-1, 1, 3)), rt.Vec3(*g.uniform(-1, 1, 3)), m[i % 3]))
+    for i in range(80):
+        p = g.uniform(-5, 5, 3)
+        lst.add(rt.Triangle(rt.Point3(*p), rt.Point3(*(p + g.uniform(-1, 1, 3))), rt.Point3(*(p + g.uniform(-1, 1, 3))), m[i % 3]))
+    o, d, tm = scenes.incoherent_rays(20000, [-6, 6, -6, 6, -6, 6], seed=6)
+    compare(rt.SceneDesc.from_world(lst), o, d, time=tm, min_hits=3000)
+    compare(rt.SceneDesc.from_world(rt.BvhNode(lst)), o, d, time=tm, min_hits=3000)
+    # per-ray intervals, including closed-interval edges
+    tmin = np.full(len(o), 0.5)
+    tmax = g.uniform(1.0, 8.0, len(o))
+    compare(rt.SceneDesc.from_world(rt.BvhNode(lst)), o, d, time=tm, tmin=tmin, tmax=tmax, min_hits=500)
+
+
+def test_book1_scene_rays():
+    world, lights, cam = scenes.book1_final(seed=0, moving=True)
+    desc = rt.SceneDesc.from_world(world, lights)
+    o, d, tm = rays_for([-12, 12, 0, 2.5, -12, 12], 60000, seed=8, spread=0.1)
+    compare(desc, o, d, time=tm, min_hits=20000)
+
+
+def test_cornell_box_instances_and_ties():
+    world, lights, cam = scenes.cornell_box()
+    desc = rt.SceneDesc.from_world(world, lights)
+    o, d, tm = scenes.incoherent_rays(60000, [1, 554, 1, 554, 1, 554], seed=9)
+    compare(desc, o, d, time=tm, min_hits=50000)
+    # adversarial: axis-parallel rays, origins on walls, rays along box faces and through box corners
+    g = np.random.default_rng(10)
+    axes = np.eye(3)[g.integers(0, 3, 6000)] * g.choice([-1.0, 1.0], (6000, 1))
+    oo = g.uniform(0, 555, (6000, 3))
+    oo[:2000, 0] = 0.0
+    oo[2000:3000, 1] = 555.0
+    compare(desc, oo, axes, min_hits=3000)
+    corners = np.array([[265.0, 0, 295], [265.0, 330, 295], [343.0, 554, 332], [213.0, 554, 227], [555.0, 555, 555], [0.0, 0, 0]])
+    tgt = corners[g.integers(0, len(corners), 6000)]
+    src = g.uniform(50, 500, (6000, 3))
+    compare(desc, src, tgt - src, min_hits=3000)
+
+
+def test_book2_scene_with_media():
+    world, lights, cam = scenes.book2_final(seed=0)
+    desc = rt.SceneDesc.from_world(world, lights)
+    o, d, tm = scenes.incoherent_rays(60000, [-200, 600, 0, 560, -200, 600], seed=11)
+    a, b = compare(desc, o, d, time=tm, seed=77, min_hits=50000)
+    kinds = set((b["prim"][b["prim"] != F.RT_REF_NONE] >> 28).tolist())
+    assert {F.RT_REF_SPHERE, F.RT_REF_QUAD, F.RT_REF_MEDIUM} <= kinds
+    # camera-like rays toward the fog-free parts
+    d2 = np.array([278.0, 278.0, 0.0]) - np.array([478.0, 278.0, -600.0]) + np.random.default_rng(2).normal(0, 120, (30000, 3))
+    o2 = np.tile([478.0, 278.0, -600.0], (30000, 1))
+    compare(desc, o2, d2, time=tm[:30000], seed=78, min_hits=20000)
+
+
+def test_cornell_smoke_media_inside_bvh():
+    world, lights, cam = scenes.cornell_smoke()
+    desc = rt.SceneDesc.from_world(world, lights)
+    o, d, tm = scenes.incoherent_rays(60000, [1, 554, 1, 554, 1, 554], seed=12)
+    a, b = compare(desc, o, d, time=tm, seed=5, min_hits=50000)
+    assert ((b["prim"] >> 28) == F.RT_REF_MEDIUM).sum() > 500
+
+
+def test_triangle_mesh_and_objmodel():
+    v = scenes.triangle_soup(20000, seed=13, edge=0.05)
+    m = rt.Lambertian(rt.Color(.5, .5, .5))
+    o, d, tm = scenes.incoherent_rays(50000, [0, 1, 0, 1, 0, 1], seed=14)
+    a, b = compare(rt.SceneDesc.from_world(rt.Mesh(v, m)), o, d, min_hits=20000)
+    a2, b2 = compare(rt.SceneDesc.from_world(rt.ObjModel(v[:600], m)), o[:4000], d[:4000], min_hits=100)
+    ico = scenes.icosphere_mesh(subdiv=3)
+    compare(rt.SceneDesc.from_world(rt.Mesh(ico, m)), o, d, min_hits=10000)
+    oo, dd, _ = scenes.primary_rays(128, [0, 1, 0, 1, 0, 1])
+    compare(rt.SceneDesc.from_world(rt.Mesh(ico, m)), oo, dd, min_hits=3000)
+
+
+def test_degenerate_batches():
+    m = rt.Lambertian(rt.Color(.5, .5, .5))
+    s = rt.Scene(rt.HittableList.with_object(rt.Sphere(rt.Point3(0, 0, -1), 0.5, m)))
+    h = s.closest_hit(np.zeros((0, 3)), np.zeros((0, 3)))
+    assert len(h["t"]) == 0
+    # 1, 63, 64, 65 rays: ragged against the 64-lane chunking
+    for n in (1, 63, 64, 65, 257):
+        o = np.zeros((n, 3))
+        d = np.tile([0, 0, -1.0], (n, 1))
+        d[::2] = [0, 0, 1.0]
+        h = s.closest_hit(o, d)
+        assert np.array_equal(h["prim"] != F.RT_REF_NONE, np.arange(n) % 2 == 1)
+        assert np.all(np.isinf(h["t"][::2]))
+    # zero direction components / zero direction: NaN slabs must behave as in aabb.rs:82-107
+    lst = rt.HittableList()
+    for x in range(8):
+        lst.add(rt.Sphere(rt.Point3(x, 0, 0), 0.4, m))
+    desc = rt.SceneDesc.from_world(rt.BvhNode(lst))
+    o = np.array([[-2, 0, 0], [-2, 0, 0], [3, 5, 0], [3, 0.4, 0], [1, 1, 1]], float)
+    d = np.array([[1, 0, 0], [0, 0, 0], [0, -1, 0], [1, 0, 0], [0, 0, 0]], float)
+    compare(desc, o, d, min_hits=2)
