@@ -130,11 +130,15 @@ __global__ void init_batch_kernel(unsigned long long* counters, unsigned long lo
 }
 
 // After a bounce: the compacted queue becomes the input of the next one.
+// The counters are read and re-written in one kernel.  A uniform-address load goes through the
+// scalar cache while the store goes through the vector path, and nothing orders the two: the
+// plain form `in = c[OUT]; c[OUT] = 0` was observed to read the zero it stores.  Exchanges make
+// every read-modify-write a single memory operation.
 __global__ void advance_kernel(unsigned long long* counters) {
-    counters[C_RAYS] += counters[C_LIVE_IN];
-    counters[C_LIVE_IN] = counters[C_LIVE_OUT];
-    counters[C_LIVE_OUT] = 0ull;
-    counters[C_WORK] = 0ull;
+    unsigned long long out = atomicExch(&counters[C_LIVE_OUT], 0ull);
+    unsigned long long in = atomicExch(&counters[C_LIVE_IN], out);
+    atomicAdd(&counters[C_RAYS], in);
+    atomicExch(&counters[C_WORK], 0ull);
 }
 
 __global__ void reset_work_kernel(unsigned long long* counters) { counters[C_WORK] = 0ull; }
