@@ -1,0 +1,235 @@
+// bvh_kernel.h -- closest hit for a world that is ONE BVH whose leaves are all primitives
+// (the reference's Mesh, mesh.rs:95-183, or a BvhNode over spheres/quads/triangles).
+//
+// Same results as the general traversal in ordered mode; built for throughput:
+//   - wide nodes (both child boxes in one 64-byte record, f32 rounded outward), nearer child first;
+//   - stack entries carry the entry distance of the deferred child, so a subtree that the closest
+//     hit has overtaken since it was pushed is dropped at pop time without fetching its node;
+//   - persistent waves with per-lane refill: a lane whose ray is finished takes the next ray from
+//     the global counter as soon as enough lanes of its wave are idle, instead of waiting for
+//     the slowest ray of a 64-ray chunk;
+//   - only (t, primitive) are produced here; the hit record is completed by finalize_hits_kernel,
+//     one coalesced pass over the batch.
+#ifndef RT_BVH_KERNEL_H
+#define RT_BVH_KERNEL_H
+
+#include "traverse.h"
+
+namespace rt {
+
+constexpr int FAST_BLOCK = 256;
+constexpr int REFILL_THRESHOLD = 40; // refill when fewer lanes than this are still traversing
+
+// Conservative f32 slab test of the fast kernel.  For one axis the entry / exit parameters of the
+// slab [b0, b1] are  t = b * inv + c  with c = -(o * inv)  (one fused multiply-add per plane; the
+// fusion only concerns this culling test, never a value that is reported).  With inv and c rounded
+// to f32 the computed t is within 2^-23 * |inv| * (|b| + |o|) of the exact one, so the near
+// parameter is lowered and the far one raised by  E = 2^-21 * |inv| * (M + |o|),  M = largest
+// |coordinate| of the BVH: the f32 test accepts every box the exact f64 test accepts.  A NaN
+// (0 * inf) is dropped by fmin/fmax, which leaves that axis unconstrained (accepting).
+struct Ray32 {
+    float inv[3];  // 1/d
+    float cn[3];   // c - E
+    float cf[3];   // c + E
+    bool neg[3];   // d < 0: the box max is the entry plane
+};
+
+RT_DEV void make_ray32(const RayD& r, float scene_extent, Ray32& q) {
+    const double o[3] = {r.ox, r.oy, r.oz}, d[3] = {r.dx, r.dy, r.dz};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double inv = 1.0 / d[k];
+        const float inv32 = (float)inv;
+        const float c = (float)(-(o[k] * inv));
+        const float e = 4.76837158203125e-07f * fabsf(inv32) * (scene_extent + fabsf((float)o[k])); // 2^-21
+        q.inv[k] = inv32;
+        q.cn[k] = c - e;
+        q.cf[k] = c + e;
+        q.neg[k] = d[k] < 0.0;
+    }
+}
+
+RT_DEV bool slab32(const float* b, const Ray32& q, float tmin_lo, float best_hi, float& near_t) {
+    const float nx = q.neg[0] ? b[1] : b[0], fx = q.neg[0] ? b[0] : b[1];
+    const float ny = q.neg[1] ? b[3] : b[2], fy = q.neg[1] ? b[2] : b[3];
+    const float nz = q.neg[2] ? b[5] : b[4], fz = q.neg[2] ? b[4] : b[5];
+    const float tnx = __builtin_fmaf(nx, q.inv[0], q.cn[0]), tfx = __builtin_fmaf(fx, q.inv[0], q.cf[0]);
+    const float tny = __builtin_fmaf(ny, q.inv[1], q.cn[1]), tfy = __builtin_fmaf(fy, q.inv[1], q.cf[1]);
+    const float tnz = __builtin_fmaf(nz, q.inv[2], q.cn[2]), tfz = __builtin_fmaf(fz, q.inv[2], q.cf[2]);
+    const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin_lo));
+    const float tf = fminf(fminf(tfx, tfy), fminf(tfz, best_hi));
+    near_t = tn;
+    return tn <= tf;
+}
+
+RT_DEV float f32_round_up(double x) { // smallest float >= x
+    float f = (float)x;
+    return ((double)f < x) ? __uint_as_float(__float_as_uint(f) + (f >= 0.0f ? 1u : 0xFFFFFFFFu)) : f;
+}
+RT_DEV float f32_round_down(double x) { // largest float <= x
+    float f = (float)x;
+    return ((double)f > x) ? __uint_as_float(__float_as_uint(f) + (f > 0.0f ? 0xFFFFFFFFu : 1u)) : f;
+}
+
+struct RayQueue {              // optional indirection: ray i of the launch is path queue[i]
+    const uint32_t* queue;     // nullptr: identity
+    const unsigned long long* count; // nullptr: use n
+};
+
+template <bool COUNT>
+__global__ __launch_bounds__(FAST_BLOCK) void bvh_closest_hit_kernel(DScene S, uint32_t root, rt_ray_batch rays,
+                                                                      unsigned long long n_in, RayQueue rq, double tmin_default,
+                                                                      float scene_extent,
+                                                                      double* out_t, uint32_t* out_prim,
+                                                                      unsigned long long* work_counter,
+                                                                      unsigned long long* stat_counters) {
+    extern __shared__ uint2 s_fast_stack[];
+    uint2* stk = s_fast_stack + threadIdx.x; // entry e of this lane: stk[e * FAST_BLOCK]
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long lane_below = (1ull << lane) - 1ull;
+    const unsigned long long n = rq.count ? *rq.count : n_in;
+
+    bool active = false;
+    bool more = true; // wave-uniform: the counter may still hold rays
+    RayD r;
+    Ray32 q;
+    float tmin32 = 0.0f, best32 = 0.0f;
+    double time = 0.0, tmin = 0.0, best_t = 0.0;
+    uint32_t best_ref = RT_REF_NONE, cur = 0;
+    unsigned long long ray_slot = 0;
+    int sp = 0;
+    uint32_t nn = 0, np = 0;
+
+    for (;;) {
+        if (more) {
+            const unsigned long long idle = __ballot(!active);
+            if (idle) {
+                const int nidle = __popcll(idle);
+                const int leader = __ffsll((long long)idle) - 1;
+                unsigned long long base = 0;
+                if ((int)lane == leader) base = atomicAdd(work_counter, (unsigned long long)nidle);
+                const uint32_t blo = (uint32_t)__shfl((int)(uint32_t)base, leader);
+                const uint32_t bhi = (uint32_t)__shfl((int)(uint32_t)(base >> 32), leader);
+                base = ((unsigned long long)bhi << 32) | blo;
+                if (!active) {
+                    const unsigned long long qi = base + (unsigned long long)__popcll(idle & lane_below);
+                    if (qi < n) {
+                        const unsigned long long i = rq.queue ? (unsigned long long)rq.queue[qi] : qi;
+                        r.ox = rays.ox[i]; r.oy = rays.oy[i]; r.oz = rays.oz[i];
+                        r.dx = rays.dx[i]; r.dy = rays.dy[i]; r.dz = rays.dz[i];
+                        make_ray32(r, scene_extent, q);
+                        time = rays.time ? rays.time[i] : 0.0;
+                        tmin = rays.tmin ? rays.tmin[i] : tmin_default;
+                        best_t = rays.tmax ? rays.tmax[i] : D_INF;
+                        tmin32 = f32_round_down(tmin);
+                        best32 = f32_round_up(best_t);
+                        best_ref = RT_REF_NONE;
+                        ray_slot = i;
+                        cur = root;
+                        sp = 0;
+                        active = true;
+                    }
+                }
+                if (base + (unsigned long long)nidle >= n) more = false;
+            }
+        }
+        if (!__any(active)) break;
+
+        while (active) {
+            const uint32_t kind = cur >> 28, idx = cur & 0x0FFFFFFFu;
+            bool pop = true;
+            if (kind == RT_REF_NODE) {
+                WNodeLoad wn;
+                load_wnode(S.wnodes, idx, wn);
+                float nl = 0.0f, nr = 0.0f;
+                const bool hl = slab32(wn.lb, q, tmin32, best32, nl);
+                const bool hr = (wn.meta & 2u) ? false : slab32(wn.rb, q, tmin32, best32, nr);
+                if (COUNT) nn += (wn.meta & 2u) ? 1u : 2u;
+                if (hl && hr) {
+                    const bool right_first = nr < nl;
+                    uint2 e;
+                    e.x = right_first ? wn.left : wn.right;
+                    e.y = __float_as_uint(right_first ? nl : nr); // a lower bound of the deferred child's entry distance
+                    stk[sp * FAST_BLOCK] = e;
+                    ++sp;
+                    cur = right_first ? wn.right : wn.left;
+                    pop = false;
+                } else if (hl) { cur = wn.left; pop = false; }
+                else if (hr) { cur = wn.right; pop = false; }
+            } else if (kind == RT_REF_TRI) {
+                const DTri* tp = S.tris + idx;
+                if (COUNT) ++np;
+                double t, u, v;
+                if (tri_test(d3p(tp->v0), d3p(tp->v1), d3p(tp->v2), r, tmin, best_t, t, u, v)) { best_t = t; best_ref = cur; best32 = f32_round_up(t); }
+            } else if (kind == RT_REF_SPHERE) {
+                const DSphere s = S.spheres[idx];
+                if (COUNT) ++np;
+                double t;
+                if (sphere_test(s, r, time, tmin, best_t, t)) { best_t = t; best_ref = cur; best32 = f32_round_up(t); }
+            } else { // RT_REF_QUAD
+                const DQuad* qd = S.quads + idx;
+                if (COUNT) ++np;
+                double t, al, be;
+                if (quad_test(*qd, r, tmin, best_t, t, al, be)) { best_t = t; best_ref = cur; best32 = f32_round_up(t); }
+            }
+            if (pop) {
+                for (;;) {
+                    if (sp == 0) {
+                        out_t[ray_slot] = best_ref == RT_REF_NONE ? D_INF : best_t;
+                        out_prim[ray_slot] = best_ref;
+                        active = false;
+                        break;
+                    }
+                    --sp;
+                    const uint2 e = stk[sp * FAST_BLOCK];
+                    // the deferred child's box was entered at e.y; closed-interval primitives may still
+                    // tie at exactly best_t, so only strictly farther subtrees are dropped
+                    if (!(__uint_as_float(e.y) > best32)) { cur = e.x; break; }
+                }
+            }
+            if (more && __popcll(__ballot(true)) < REFILL_THRESHOLD) break;
+        }
+    }
+    if (COUNT) {
+        atomicAdd(&stat_counters[0], (unsigned long long)nn);
+        atomicAdd(&stat_counters[1], (unsigned long long)np);
+    }
+}
+
+// Completes HitRecord fields for a batch whose (t, prim) are already written (transform context 0).
+__global__ __launch_bounds__(256) void finalize_hits_kernel(DScene S, rt_ray_batch rays, unsigned long long n, rt_hit_batch hits) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t prim = hits.prim[i];
+    if (prim == RT_REF_NONE) {
+        if (hits.u) hits.u[i] = 0.0;
+        if (hits.v) hits.v[i] = 0.0;
+        if (hits.front_face) hits.front_face[i] = 0;
+        if (hits.mat) hits.mat[i] = -1;
+        if (hits.nx) hits.nx[i] = 0.0;
+        if (hits.ny) hits.ny[i] = 0.0;
+        if (hits.nz) hits.nz[i] = 0.0;
+        if (hits.px) hits.px[i] = 0.0;
+        if (hits.py) hits.py[i] = 0.0;
+        if (hits.pz) hits.pz[i] = 0.0;
+        return;
+    }
+    WorldRay w{rays.ox, rays.oy, rays.oz, rays.dx, rays.dy, rays.dz, i};
+    Best b;
+    b.t = hits.t[i]; b.ref = prim; b.ctx = 0;
+    HitRec h;
+    finalize(S, w, rays.time ? rays.time[i] : 0.0, b, h);
+    if (hits.u) hits.u[i] = h.u;
+    if (hits.v) hits.v[i] = h.v;
+    if (hits.front_face) hits.front_face[i] = h.front_face ? 1 : 0;
+    if (hits.mat) hits.mat[i] = h.mat;
+    if (hits.nx) hits.nx[i] = h.normal.x;
+    if (hits.ny) hits.ny[i] = h.normal.y;
+    if (hits.nz) hits.nz[i] = h.normal.z;
+    if (hits.px) hits.px[i] = h.p.x;
+    if (hits.py) hits.py[i] = h.p.y;
+    if (hits.pz) hits.pz[i] = h.p.z;
+}
+
+} // namespace rt
+#endif

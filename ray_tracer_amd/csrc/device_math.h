@@ -159,6 +159,35 @@ RT_DEV bool slab_test(const double* b, const RayD& r, double lo, double hi) {
     return true;
 }
 
+// The same test on an f32 box that contains the node's f64 box (WNode); `near_t` is the clipped
+// entry distance.  Every operation is monotone in the box coordinates, so this test passes
+// whenever slab_test passes on the exact box: the ordered traversal visits a superset.
+RT_DEV bool slab_test_wide(const float* b, const RayD& r, double lo, double hi, double& near_t) {
+    {
+        double t0 = ((double)b[0] - r.ox) * r.ix, t1 = ((double)b[1] - r.ox) * r.ix;
+        double tmn = t0 < t1 ? t0 : t1, tmx = t0 < t1 ? t1 : t0;
+        if (tmn > lo) lo = tmn;
+        if (tmx < hi) hi = tmx;
+        if (hi <= lo) return false;
+    }
+    {
+        double t0 = ((double)b[2] - r.oy) * r.iy, t1 = ((double)b[3] - r.oy) * r.iy;
+        double tmn = t0 < t1 ? t0 : t1, tmx = t0 < t1 ? t1 : t0;
+        if (tmn > lo) lo = tmn;
+        if (tmx < hi) hi = tmx;
+        if (hi <= lo) return false;
+    }
+    {
+        double t0 = ((double)b[4] - r.oz) * r.iz, t1 = ((double)b[5] - r.oz) * r.iz;
+        double tmn = t0 < t1 ? t0 : t1, tmx = t0 < t1 ? t1 : t0;
+        if (tmn > lo) lo = tmn;
+        if (tmx < hi) hi = tmx;
+        if (hi <= lo) return false;
+    }
+    near_t = lo;
+    return true;
+}
+
 // Sphere::hit (sphere.rs:72-98): the accepted root, open interval (tmin, tmax).
 RT_DEV bool sphere_test(const DSphere& s, const RayD& r, double time, double tmin, double tmax, double& t_out) {
     D3 center = d3(s.c[0], s.c[1], s.c[2]) + time * d3(s.dc[0], s.dc[1], s.dc[2]);

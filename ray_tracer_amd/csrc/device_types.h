@@ -56,6 +56,17 @@ struct alignas(16) DTriAux {   // 32 B: read once per accepted hit
 
 typedef rt_bvh_node DNode;     // 64 B
 
+// Wide node of the ordered traversal: the boxes of BOTH children of BVH node i, rounded outward
+// to f32, so one 64-byte fetch decides both subtrees before either is entered.
+struct alignas(16) WNode {     // 64 B
+    float lb[6];               // left child box: xmin xmax ymin ymax zmin zmax
+    float rb[6];               // right child box
+    uint32_t left, right;      // same references as DNode
+    uint32_t meta;             // bit 0: subtree holds a constant medium (keep reference order);
+                               // bit 1: right is the same object as left (bvh.rs:41-44)
+    uint32_t _pad;
+};
+
 struct DList { uint32_t first, count; };
 
 struct alignas(8) DXform {     // hittable.rs:61-65 / 97-102
@@ -93,6 +104,7 @@ struct DLight { uint32_t kind; uint32_t index; }; // RT_REF_SPHERE / RT_REF_QUAD
 // Pointers are device pointers once uploaded (host pointers in a HOST_ONLY scene).
 struct DScene {
     const DNode* nodes;
+    const WNode* wnodes;
     const DSphere* spheres;
     const DQuad* quads;
     const DTri* tris;

@@ -73,13 +73,20 @@ inline bool box_has_nan(const Box& a) {
 
 struct Item { Box box; uint32_t ref; uint32_t medium; };
 
+// f64 -> f32 rounded away from the box interior, so the f32 box contains the f64 box.
+inline float f32_down(double x) { float f = (float)x; if ((double)f > x) f = std::nextafterf(f, -std::numeric_limits<float>::infinity()); return f; }
+inline float f32_up(double x) { float f = (float)x; if ((double)f < x) f = std::nextafterf(f, std::numeric_limits<float>::infinity()); return f; }
+inline void widen(const double* b, float* o) {
+    for (int k = 0; k < 3; ++k) { o[2 * k] = f32_down(b[2 * k]); o[2 * k + 1] = f32_up(b[2 * k + 1]); }
+}
+
 uint64_t bvh_node_count(uint64_t n) { // N(1)=N(2)=1, N(n)=1+N(n/2)+N(n-n/2)
     if (n <= 2) return 1;
     return 1 + bvh_node_count(n / 2) + bvh_node_count(n - n / 2);
 }
 
 // Builds the subtree for items[start,end) into nodes[at ...]; returns has-medium flag.
-uint32_t build_bvh(std::vector<Item>& items, size_t start, size_t end, DNode* nodes, uint64_t base, uint64_t at, int depth) {
+uint32_t build_bvh(std::vector<Item>& items, size_t start, size_t end, DNode* nodes, WNode* wnodes, uint64_t base, uint64_t at, int depth) {
     size_t span = end - start;
     Box bbox = box_empty();
     for (size_t i = start; i < end; ++i) bbox = box_union(bbox, items[i].box);
@@ -88,13 +95,19 @@ uint32_t build_bvh(std::vector<Item>& items, size_t start, size_t end, DNode* no
     for (int k = 0; k < 6; ++k) n.bounds[k] = bbox.b[k];
     n._pad = 0;
     uint32_t medium = 0;
+    WNode& wn = wnodes[at];
+    wn._pad = 0;
     if (span == 1) {
         n.left = n.right = items[start].ref;
         medium = items[start].medium;
+        widen(items[start].box.b, wn.lb);
+        widen(items[start].box.b, wn.rb);
     } else if (span == 2) {
         n.left = items[start].ref;
         n.right = items[start + 1].ref;
         medium = items[start].medium | items[start + 1].medium;
+        widen(items[start].box.b, wn.lb);
+        widen(items[start + 1].box.b, wn.rb);
     } else {
         std::vector<uint32_t> order(span);
         std::iota(order.begin(), order.end(), 0u);
@@ -114,16 +127,20 @@ uint32_t build_bvh(std::vector<Item>& items, size_t start, size_t end, DNode* no
         n.right = make_ref(RT_REF_NODE, (uint32_t)(base + right_at));
         uint32_t ml, mr;
         if (depth < 4 && span > 8192) { // the two halves are independent (bvh.rs:64-67 uses rayon::join)
-            auto fut = std::async(std::launch::async, [&]() { return build_bvh(items, start, mid, nodes, base, left_at, depth + 1); });
-            mr = build_bvh(items, mid, end, nodes, base, right_at, depth + 1);
+            auto fut = std::async(std::launch::async, [&]() { return build_bvh(items, start, mid, nodes, wnodes, base, left_at, depth + 1); });
+            mr = build_bvh(items, mid, end, nodes, wnodes, base, right_at, depth + 1);
             ml = fut.get();
         } else {
-            ml = build_bvh(items, start, mid, nodes, base, left_at, depth + 1);
-            mr = build_bvh(items, mid, end, nodes, base, right_at, depth + 1);
+            ml = build_bvh(items, start, mid, nodes, wnodes, base, left_at, depth + 1);
+            mr = build_bvh(items, mid, end, nodes, wnodes, base, right_at, depth + 1);
         }
         medium = ml | mr;
+        widen(nodes[left_at].bounds, wn.lb);
+        widen(nodes[right_at].bounds, wn.rb);
     }
     n.flags = medium ? 1u : 0u;
+    wn.left = n.left; wn.right = n.right;
+    wn.meta = (medium ? 1u : 0u) | (n.left == n.right ? 2u : 0u);
     return medium;
 }
 
@@ -134,6 +151,7 @@ struct Flattener {
     std::map<std::pair<int32_t, int32_t>, uint32_t> memo; // (object, ctx) -> ref
     std::vector<uint8_t> obj_medium;                     // object subtree contains a medium
     std::vector<int32_t> need_node;
+    std::map<uint32_t, bool> bvh_prim_only;               // BVH root ref -> every leaf is a sphere/quad/triangle
 
     Flattener(const rt_scene_desc* desc, FlatScene& out, std::string& e) : d(desc), f(out), err(e) {}
 
@@ -426,8 +444,17 @@ struct Flattener {
             uint64_t base = f.nodes.size();
             if (base + count >= (1ull << 28)) return fail(RT_E_TOO_LARGE, "bvh: more than 2^28 nodes");
             f.nodes.resize(base + count);
-            build_bvh(items, 0, items.size(), f.nodes.data() + base, base, 0, 0);
+            f.wnodes.resize(base + count);
+            build_bvh(items, 0, items.size(), f.nodes.data() + base, f.wnodes.data() + base, base, 0, 0);
             ref = make_ref(RT_REF_NODE, (uint32_t)base);
+            {
+                bool prim_only = true;
+                for (auto& i2 : items) {
+                    uint32_t k = RT_REF_KIND(i2.ref);
+                    if (k != RT_REF_SPHERE && k != RT_REF_QUAD && k != RT_REF_TRI) { prim_only = false; break; }
+                }
+                bvh_prim_only[ref] = prim_only;
+            }
             break;
         }
         case RT_OBJ_TRANSLATE: case RT_OBJ_ROTATE_Y: {
@@ -545,6 +572,15 @@ struct Flattener {
             f.n_lights = -1;
         }
         need_node.assign(f.nodes.size(), -1);
+        {
+            uint32_t r = f.world;
+            if (RT_REF_KIND(r) == RT_REF_LIST && f.lists[RT_REF_INDEX(r)].count == 1) r = f.list_items[f.lists[RT_REF_INDEX(r)].first];
+            auto it = bvh_prim_only.find(r);
+            if (RT_REF_KIND(r) == RT_REF_NODE && it != bvh_prim_only.end() && it->second) {
+                f.fast_root = r;
+                f.fast_stack = (uint32_t)need(r) + 1;
+            }
+        }
         f.max_stack = (uint32_t)need(f.world) + 1;
         if (f.max_stack > (uint32_t)STACK_MAX) return fail(RT_E_TOO_LARGE, "scene needs a deeper traversal stack than the kernels carry (32 entries)");
         return RT_OK;

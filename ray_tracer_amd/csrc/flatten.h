@@ -14,6 +14,7 @@ struct Box { // aabb.rs:10-14 as xmin xmax ymin ymax zmin zmax
 
 struct FlatScene {
     std::vector<DNode> nodes;
+    std::vector<WNode> wnodes;
     std::vector<DSphere> spheres;
     std::vector<DQuad> quads;
     std::vector<DTri> tris;
@@ -33,6 +34,8 @@ struct FlatScene {
     int32_t n_lights = -1;
     int32_t lights_is_list = 0;
     uint32_t max_stack = 0;
+    uint32_t fast_root = RT_REF_NONE; // set when the world is one BVH whose leaves are all primitives
+    uint32_t fast_stack = 0;          // stack entries the primitive-BVH kernel needs
     bool has_medium = false;
     Box world_bounds;
 };

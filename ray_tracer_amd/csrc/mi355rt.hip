@@ -21,6 +21,7 @@
 
 #include "flatten.h"
 #include "shade.h"
+#include "bvh_kernel.h"
 
 using namespace rt;
 
@@ -64,7 +65,7 @@ __device__ __forceinline__ unsigned long long wave_fetch(unsigned long long* cou
     return ((unsigned long long)hi << 32) | lo;
 }
 
-template <bool COUNT>
+template <bool COUNT, bool ORDERED>
 __global__ __launch_bounds__(BLOCK) void closest_hit_kernel(DScene S, rt_ray_batch rays, unsigned long long n, rt_hit_batch hits,
                                                             unsigned long long seed, unsigned long long* counters) {
     __shared__ uint32_t s_stack[STACK_MAX * BLOCK];
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(BLOCK) void closest_hit_kernel(DScene S, rt_ray_bat
             b.t = rays.tmax ? rays.tmax[i] : D_INF;
             b.ref = RT_REF_NONE; b.ctx = 0;
             Rng g{seed, 2u, (uint32_t)i, (uint32_t)(i >> 32), 0u};
-            traverse<true, COUNT>(S, S.world, r, 0, w, time, tmin, b, stk, 0, &g, nn, np);
+            traverse<true, COUNT, ORDERED>(S, S.world, r, 0, w, time, tmin, b, stk, 0, &g, nn, np);
             if (b.ref != RT_REF_NONE) {
                 HitRec h;
                 finalize(S, w, time, b, h);
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(BLOCK) void extend_kernel(DScene S, PathState ps, i
             int32_t i = bg.x0 + (int32_t)(pix % (uint32_t)bg.tw);
             int32_t j = bg.y0 + (int32_t)(pix / (uint32_t)bg.tw);
             Rng g{seed, 0u, (uint32_t)(j * image_width + i), (uint32_t)(bg.sample0 + (int32_t)s_local), ps.rng_index[p]};
-            traverse<true, false>(S, S.world, r, 0, w, time, 0.001, b, stk, 0, &g, nn, np); // Interval::new(0.001, INFINITY) (camera.rs:258)
+            traverse<true, false, true>(S, S.world, r, 0, w, time, 0.001, b, stk, 0, &g, nn, np); // Interval::new(0.001, INFINITY) (camera.rs:258)
             ps.hit_t[p] = b.t;
             ps.hit_ref[p] = b.ref;
             ps.hit_ctx[p] = b.ctx;
@@ -293,6 +294,9 @@ struct rt_scene {
     bool hit_timed = false, render_timed = false;
     rt_counters counters{};
     int grid_blocks = 0;
+    int fast_grid_blocks = 0;
+    size_t fast_lds = 0;
+    float fast_extent = 0.0f; // largest |coordinate| of the world box (error bound of the f32 slab test)
     // render workspace
     PathState ps{};
     uint64_t ws_paths = 0;
@@ -329,18 +333,27 @@ int pick_grid(rt_scene* s) {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, s->device));
     int per_cu = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, closest_hit_kernel<false>, BLOCK, 0));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, closest_hit_kernel<false, true>, BLOCK, 0));
     int per_cu2 = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, extend_kernel, BLOCK, 0));
     per_cu = std::max(1, std::min(per_cu, per_cu2));
     s->grid_blocks = prop.multiProcessorCount * per_cu;
+    if (s->flat.fast_root != RT_REF_NONE) {
+        s->fast_lds = (size_t)s->flat.fast_stack * FAST_BLOCK * sizeof(uint2);
+        double ext = 0.0;
+        for (double v : s->flat.world_bounds.b) ext = std::max(ext, std::fabs(v));
+        s->fast_extent = (float)(ext * 1.0000001);
+        int fast_per_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fast_per_cu, bvh_closest_hit_kernel<false>, FAST_BLOCK, s->fast_lds));
+        s->fast_grid_blocks = prop.multiProcessorCount * std::max(1, fast_per_cu);
+    }
     return RT_OK;
 }
 
 void fill_host_dscene(rt_scene* s) {
     FlatScene& f = s->flat;
     DScene& d = s->dev;
-    d.nodes = f.nodes.data(); d.spheres = f.spheres.data(); d.quads = f.quads.data(); d.tris = f.tris.data();
+    d.nodes = f.nodes.data(); d.wnodes = f.wnodes.data(); d.spheres = f.spheres.data(); d.quads = f.quads.data(); d.tris = f.tris.data();
     d.tri_aux = f.tri_aux.data(); d.lists = f.lists.data(); d.list_items = f.list_items.data(); d.xforms = f.xforms.data();
     d.media = f.media.data(); d.materials = f.materials.data(); d.textures = f.textures.data(); d.images = f.images.data();
     d.image_bytes = f.image_bytes.data(); d.perlins = f.perlins.data(); d.lights = f.lights.data();
@@ -352,6 +365,7 @@ int upload_scene(rt_scene* s) {
     DScene& d = s->dev;
     int rc;
     if ((rc = upload(s, f.nodes, &d.nodes))) return rc;
+    if ((rc = upload(s, f.wnodes, &d.wnodes))) return rc;
     if ((rc = upload(s, f.spheres, &d.spheres))) return rc;
     if ((rc = upload(s, f.quads, &d.quads))) return rc;
     if ((rc = upload(s, f.tris, &d.tris))) return rc;
@@ -421,10 +435,33 @@ int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit
     uint64_t waves = (n + 63) / 64;
     int blocks = (int)std::min<uint64_t>((uint64_t)s->grid_blocks, (waves + (BLOCK / 64) - 1) / (BLOCK / 64));
     HIP_TRY(hipEventRecord(s->ev_hit0, st));
-    if (flags & RT_HIT_COUNTERS)
-        hipLaunchKernelGGL(closest_hit_kernel<true>, dim3(blocks), dim3(BLOCK), 0, st, s->dev, *rays, (unsigned long long)n, *hits, (unsigned long long)seed, s->d_counters);
-    else
-        hipLaunchKernelGGL(closest_hit_kernel<false>, dim3(blocks), dim3(BLOCK), 0, st, s->dev, *rays, (unsigned long long)n, *hits, (unsigned long long)seed, s->d_counters);
+    const bool count = flags & RT_HIT_COUNTERS, ordered = flags & RT_HIT_ORDERED;
+    if (ordered && s->flat.fast_root != RT_REF_NONE) {
+        // the world is one BVH over primitives: dedicated traversal kernel + one pass that completes the records
+        int fblocks = (int)std::min<uint64_t>((uint64_t)s->fast_grid_blocks, (waves + (FAST_BLOCK / 64) - 1) / (FAST_BLOCK / 64));
+        RayQueue rq{nullptr, nullptr};
+        if (count)
+            hipLaunchKernelGGL(bvh_closest_hit_kernel<true>, dim3(fblocks), dim3(FAST_BLOCK), s->fast_lds, st, s->dev, s->flat.fast_root, *rays,
+                               (unsigned long long)n, rq, 0.001, s->fast_extent, hits->t, hits->prim, s->d_counters + C_WORK, s->d_counters + C_NODES);
+        else
+            hipLaunchKernelGGL(bvh_closest_hit_kernel<false>, dim3(fblocks), dim3(FAST_BLOCK), s->fast_lds, st, s->dev, s->flat.fast_root, *rays,
+                               (unsigned long long)n, rq, 0.001, s->fast_extent, hits->t, hits->prim, s->d_counters + C_WORK, s->d_counters + C_NODES);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(s->ev_hit1, st));
+        if (hits->u || hits->v || hits->front_face || hits->mat || hits->nx || hits->ny || hits->nz || hits->px || hits->py || hits->pz)
+            hipLaunchKernelGGL(finalize_hits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s->dev, *rays, (unsigned long long)n, *hits);
+        HIP_TRY(hipGetLastError());
+        s->hit_timed = true;
+        s->counters.rays += n;
+        return RT_OK;
+    }
+    auto launch = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(BLOCK), 0, st, s->dev, *rays, (unsigned long long)n, *hits, (unsigned long long)seed, s->d_counters);
+    };
+    if (count && ordered) launch(closest_hit_kernel<true, true>);
+    else if (count) launch(closest_hit_kernel<true, false>);
+    else if (ordered) launch(closest_hit_kernel<false, true>);
+    else launch(closest_hit_kernel<false, false>);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev_hit1, st));
     s->hit_timed = true;

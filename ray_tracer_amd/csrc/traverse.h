@@ -74,10 +74,27 @@ RT_DEV void load_node(const DNode* nodes, uint32_t idx, NodeLoad& n) {
     n.left = d.x; n.right = d.y; n.flags = d.z; n.pad = d.w;
 }
 
+struct WNodeLoad { float lb[6]; float rb[6]; uint32_t left, right, meta, pad; };
+RT_DEV void load_wnode(const WNode* wnodes, uint32_t idx, WNodeLoad& n) {
+    const float4* p = reinterpret_cast<const float4*>(wnodes + idx);
+    float4 a = p[0], b = p[1], c = p[2];
+    const uint4 d = *reinterpret_cast<const uint4*>(p + 3);
+    n.lb[0] = a.x; n.lb[1] = a.y; n.lb[2] = a.z; n.lb[3] = a.w; n.lb[4] = b.x; n.lb[5] = b.y;
+    n.rb[0] = b.z; n.rb[1] = b.w; n.rb[2] = c.x; n.rb[3] = c.y; n.rb[4] = c.z; n.rb[5] = c.w;
+    n.left = d.x; n.right = d.y; n.meta = d.z; n.pad = d.w;
+}
+
 // Closest hit of `root` for the lane's ray over (tmin, best.t].  TOP = the world query
 // (constant media allowed); the nested boundary queries of a medium run with TOP = false.
 // `stk` points at this lane's column of the LDS stack, entries are BLOCK words apart.
-template <bool TOP, bool COUNT>
+//
+// ORDERED = false is the reference's visit order on the exact f64 nodes.  ORDERED = true uses the
+// wide nodes: both child boxes are tested at the parent and the nearer child is entered first.
+// The closest hit is the same; only which of several primitives hit at exactly equal t is
+// reported may differ.  Subtrees that hold a constant medium always take the exact
+// reference-order path, because a medium draws a random number per visit
+// (constant_medium.rs:90) and whether it is visited must not depend on the traversal variant.
+template <bool TOP, bool COUNT, bool ORDERED>
 __device__ __forceinline__ void traverse(const DScene& S, uint32_t root, RayD ray, int32_t ctx, const WorldRay& w,
                                          double time, double tmin, Best& best, uint32_t* stk, int sp0, Rng* rng,
                                          uint32_t& n_nodes, uint32_t& n_prims) {
@@ -86,7 +103,27 @@ __device__ __forceinline__ void traverse(const DScene& S, uint32_t root, RayD ra
     for (;;) {
         const uint32_t kind = cur >> 28, idx = cur & 0x0FFFFFFFu;
         bool pop = true;
-        if (kind == RT_REF_NODE) {
+        bool wide_done = false;
+        if (ORDERED && kind == RT_REF_NODE) {
+            WNodeLoad wn;
+            load_wnode(S.wnodes, idx, wn);
+            if (!(wn.meta & 1u)) {
+                wide_done = true;
+                double nl = 0.0, nr = 0.0;
+                const bool hl = slab_test_wide(wn.lb, ray, tmin, best.t, nl);
+                const bool hr = (wn.meta & 2u) ? false : slab_test_wide(wn.rb, ray, tmin, best.t, nr);
+                if (COUNT) n_nodes += (wn.meta & 2u) ? 1u : 2u;
+                if (hl && hr) {
+                    const bool right_first = nr < nl;
+                    stk[sp * BLOCK] = right_first ? wn.left : wn.right; ++sp;
+                    cur = right_first ? wn.right : wn.left;
+                    pop = false;
+                } else if (hl) { cur = wn.left; pop = false; }
+                else if (hr) { cur = wn.right; pop = false; }
+            }
+        }
+        if (wide_done) {
+        } else if (kind == RT_REF_NODE) {
             NodeLoad n;
             load_node(S.nodes, idx, n);
             if (COUNT) ++n_nodes;
@@ -145,7 +182,7 @@ __device__ __forceinline__ void traverse(const DScene& S, uint32_t root, RayD ra
                 for (int pass = 0; pass < 2 && ok; ++pass) {
                     Best b; b.t = D_INF; b.ref = RT_REF_NONE; b.ctx = 0;
                     double lo = pass == 0 ? -D_INF : t1 + 0.0001; // Interval::UNIVERSE, then [rec1.t + 0.0001, inf)
-                    traverse<false, COUNT>(S, m.boundary, ray, ctx, w, time, lo, b, stk, sp, nullptr, n_nodes, n_prims);
+                    traverse<false, COUNT, ORDERED>(S, m.boundary, ray, ctx, w, time, lo, b, stk, sp, nullptr, n_nodes, n_prims);
                     if (b.ref == RT_REF_NONE) ok = false;
                     else if (pass == 0) t1 = b.t; else t2 = b.t;
                 }

@@ -26,6 +26,15 @@ def compare(desc, o, d, time=None, tmin=None, tmax=None, seed=0, min_hits=1, fla
     # A constant-medium hit goes through ln(U) (constant_medium.rs:90): the device and glibc logarithms
     # may differ in the last ulps, so its t and p are held to 1e-12 relative instead of bit equality.
     medium = (b["prim"] >> 28) == F.RT_REF_MEDIUM
+    if flags & F.RT_HIT_ORDERED:
+        # near-first traversal: the closest t is the same bit for bit; where several primitives are hit
+        # at exactly that t another one of them may be reported (bar: ties within 1e-6 relative)
+        tie = (a["prim"] != b["prim"])
+        assert np.array_equal(a["t"][tie & ~medium], b["t"][tie & ~medium])
+        assert tie.mean() < 0.02, tie.mean()
+        for f in a:
+            a[f] = a[f][~tie]; b[f] = b[f][~tie]
+        medium = medium[~tie]
     assert np.array_equal(a["prim"], b["prim"])
     for f in EXACT:
         same = (a[f] == b[f]) | ((a[f] != a[f]) & (b[f] != b[f]))
@@ -147,6 +156,37 @@ def test_triangle_mesh_and_objmodel():
     compare(rt.SceneDesc.from_world(rt.Mesh(ico, m)), o, d, min_hits=10000)
     oo, dd, _ = scenes.primary_rays(128, [0, 1, 0, 1, 0, 1])
     compare(rt.SceneDesc.from_world(rt.Mesh(ico, m)), oo, dd, min_hits=3000)
+
+
+def test_ordered_traversal_matches_reference_order():
+    """RT_HIT_ORDERED (wide f32 nodes, nearer child first) against the oracle's reference-order result."""
+    m = rt.Lambertian(rt.Color(.5, .5, .5))
+    v = scenes.triangle_soup(40000, seed=21, edge=0.04)
+    o, d, tm = scenes.incoherent_rays(100000, [0, 1, 0, 1, 0, 1], seed=22)
+    compare(rt.SceneDesc.from_world(rt.Mesh(v, m)), o, d, min_hits=50000, flags=F.RT_HIT_ORDERED)
+    world, lights, cam = scenes.book1_final(seed=0, moving=True)
+    o2, d2, tm2 = rays_for([-12, 12, 0, 2.5, -12, 12], 60000, seed=8, spread=0.1)
+    compare(rt.SceneDesc.from_world(world, lights), o2, d2, time=tm2, min_hits=20000, flags=F.RT_HIT_ORDERED)
+    for build in (lambda: scenes.book2_final(seed=0), scenes.cornell_smoke, scenes.cornell_box, scenes.quads):
+        world, lights, cam = build()
+        desc = rt.SceneDesc.from_world(world, lights)
+        b = rt.Scene(desc, host_only=True).info().world_bounds
+        o3, d3, tm3 = rays_for([b[k] for k in range(6)] if np.isfinite(b[0]) and abs(b[0]) < 1e4 else [-200, 600, 0, 560, -200, 600],
+                               40000, seed=23, spread=0.05)
+        compare(desc, o3, d3, time=tm3, seed=9, min_hits=3000, flags=F.RT_HIT_ORDERED)
+    # GPU-side counters: the ordered traversal must visit far fewer boxes than the reference order
+    desc = rt.SceneDesc.from_world(rt.Mesh(v, m))
+    g = rt.Scene(desc)
+    g.closest_hit(o, d, flags=F.RT_HIT_COUNTERS)
+    ref = g.counters()
+    ctr = {}
+    O.OracleScene(desc).closest_hit(o, d, counters=ctr)
+    # same boxes tested as the oracle's recursion; the one-object-span duplicate test (bvh.rs:41-44) is skipped
+    assert ref.node_visits == ctr["node_visits"] and ref.prim_tests <= ctr["prim_tests"]
+    g.reset_counters()
+    g.closest_hit(o, d, flags=F.RT_HIT_COUNTERS | F.RT_HIT_ORDERED)
+    fast = g.counters()
+    assert fast.node_visits < 0.8 * ref.node_visits and fast.prim_tests < 0.5 * ref.prim_tests
 
 
 def test_degenerate_batches():
