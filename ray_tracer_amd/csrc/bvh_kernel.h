@@ -2,9 +2,12 @@
 // (the reference's Mesh, mesh.rs:95-183, or a BvhNode over spheres/quads/triangles).
 //
 // Same results as the general traversal in ordered mode; built for throughput:
-//   - wide nodes (both child boxes in one 64-byte record, f32 rounded outward), nearer child first;
+//   - 4-wide nodes: two levels of the binary tree in one 128-byte record (one cache line), boxes
+//     rounded outward to f32 and tested with a conservative f32 slab test; children are entered
+//     nearest first.  Half as many dependent fetches per ray as the binary tree;
 //   - stack entries carry the entry distance of the deferred child, so a subtree that the closest
 //     hit has overtaken since it was pushed is dropped at pop time without fetching its node;
+//     the newest 8 entries per lane sit in LDS, deeper ones spill to HBM (rare);
 //   - persistent waves with per-lane refill: a lane whose ray is finished takes the next ray from
 //     the global counter as soon as enough lanes of its wave are idle, instead of waiting for
 //     the slowest ray of a 64-ray chunk;
@@ -76,15 +79,54 @@ struct RayQueue {              // optional indirection: ray i of the launch is p
     const unsigned long long* count; // nullptr: use n
 };
 
-template <bool COUNT>
-__global__ __launch_bounds__(FAST_BLOCK) void bvh_closest_hit_kernel(DScene S, uint32_t root, rt_ray_batch rays,
-                                                                      unsigned long long n_in, RayQueue rq, double tmin_default,
-                                                                      float scene_extent,
-                                                                      double* out_t, uint32_t* out_prim,
-                                                                      unsigned long long* work_counter,
-                                                                      unsigned long long* stat_counters) {
-    extern __shared__ uint2 s_fast_stack[];
-    uint2* stk = s_fast_stack + threadIdx.x; // entry e of this lane: stk[e * FAST_BLOCK]
+constexpr int LDS_STACK = 8;   // stack entries per lane held in LDS (power of two); deeper ones spill to HBM
+
+// Per-lane traversal stack: the newest LDS_STACK entries live in LDS ([slot][thread], 8 bytes each),
+// older ones in a per-thread column of `spill` (HBM, [entry][thread], coalesced across the wave).
+struct LaneStack {
+    uint2* lds;                // this lane's column: slot s at lds[s * FAST_BLOCK]
+    uint2* spill;              // this lane's column: entry k at spill[k * spill_stride]
+    size_t spill_stride;
+    int sp;                    // entries on the stack
+    int base;                  // oldest entry still in LDS
+    RT_DEV void reset() { sp = 0; base = 0; }
+    RT_DEV void push(uint32_t ref, float near_t) {
+        if (sp - base == LDS_STACK) {
+            spill[(size_t)base * spill_stride] = lds[(base & (LDS_STACK - 1)) * FAST_BLOCK];
+            ++base;
+        }
+        uint2 e;
+        e.x = ref; e.y = __float_as_uint(near_t);
+        lds[(sp & (LDS_STACK - 1)) * FAST_BLOCK] = e;
+        ++sp;
+    }
+    RT_DEV uint2 pop() { // precondition: sp > 0
+        --sp;
+        if (sp < base) { base = sp; return spill[(size_t)sp * spill_stride]; }
+        return lds[(sp & (LDS_STACK - 1)) * FAST_BLOCK];
+    }
+};
+
+RT_DEV void order2(float& ka, uint32_t& ra, float& kb, uint32_t& rb) { // ascending by key
+    const bool sw = kb < ka;
+    const float k0 = sw ? kb : ka, k1 = sw ? ka : kb;
+    const uint32_t r0 = sw ? rb : ra, r1 = sw ? ra : rb;
+    ka = k0; kb = k1; ra = r0; rb = r1;
+}
+
+// PRIM: RT_REF_TRI / RT_REF_SPHERE / RT_REF_QUAD when every leaf has that kind, 0 for mixed leaves.
+template <int PRIM, bool COUNT>
+__global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, uint32_t root, rt_ray_batch rays,
+                                                                       unsigned long long n_in, RayQueue rq, double tmin_default,
+                                                                       float scene_extent, double* out_t, uint32_t* out_prim,
+                                                                       unsigned long long* work_counter,
+                                                                       unsigned long long* stat_counters, uint2* spill) {
+    __shared__ uint2 s_fast_stack[LDS_STACK * FAST_BLOCK];
+    LaneStack st;
+    st.lds = s_fast_stack + threadIdx.x;
+    st.spill_stride = (size_t)gridDim.x * FAST_BLOCK;
+    st.spill = spill + (size_t)blockIdx.x * FAST_BLOCK + threadIdx.x;
+    st.reset();
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lane_below = (1ull << lane) - 1ull;
     const unsigned long long n = rq.count ? *rq.count : n_in;
@@ -97,7 +139,6 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh_closest_hit_kernel(DScene S, u
     double time = 0.0, tmin = 0.0, best_t = 0.0;
     uint32_t best_ref = RT_REF_NONE, cur = 0;
     unsigned long long ray_slot = 0;
-    int sp = 0;
     uint32_t nn = 0, np = 0;
 
     for (;;) {
@@ -126,7 +167,7 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh_closest_hit_kernel(DScene S, u
                         best_ref = RT_REF_NONE;
                         ray_slot = i;
                         cur = root;
-                        sp = 0;
+                        st.reset();
                         active = true;
                     }
                 }
@@ -139,29 +180,48 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh_closest_hit_kernel(DScene S, u
             const uint32_t kind = cur >> 28, idx = cur & 0x0FFFFFFFu;
             bool pop = true;
             if (kind == RT_REF_NODE) {
-                WNodeLoad wn;
-                load_wnode(S.wnodes, idx, wn);
-                float nl = 0.0f, nr = 0.0f;
-                const bool hl = slab32(wn.lb, q, tmin32, best32, nl);
-                const bool hr = (wn.meta & 2u) ? false : slab32(wn.rb, q, tmin32, best32, nr);
-                if (COUNT) nn += (wn.meta & 2u) ? 1u : 2u;
-                if (hl && hr) {
-                    const bool right_first = nr < nl;
-                    uint2 e;
-                    e.x = right_first ? wn.left : wn.right;
-                    e.y = __float_as_uint(right_first ? nl : nr); // a lower bound of the deferred child's entry distance
-                    stk[sp * FAST_BLOCK] = e;
-                    ++sp;
-                    cur = right_first ? wn.right : wn.left;
+                const float4* qp = reinterpret_cast<const float4*>(S.qnodes + idx);
+                const float4 lox = qp[0], loy = qp[1], loz = qp[2], hix = qp[3], hiy = qp[4], hiz = qp[5];
+                const uint4 ch = *reinterpret_cast<const uint4*>(qp + 6);
+                const float nx[4] = {q.neg[0] ? hix.x : lox.x, q.neg[0] ? hix.y : lox.y, q.neg[0] ? hix.z : lox.z, q.neg[0] ? hix.w : lox.w};
+                const float fx[4] = {q.neg[0] ? lox.x : hix.x, q.neg[0] ? lox.y : hix.y, q.neg[0] ? lox.z : hix.z, q.neg[0] ? lox.w : hix.w};
+                const float ny[4] = {q.neg[1] ? hiy.x : loy.x, q.neg[1] ? hiy.y : loy.y, q.neg[1] ? hiy.z : loy.z, q.neg[1] ? hiy.w : loy.w};
+                const float fy[4] = {q.neg[1] ? loy.x : hiy.x, q.neg[1] ? loy.y : hiy.y, q.neg[1] ? loy.z : hiy.z, q.neg[1] ? loy.w : hiy.w};
+                const float nz[4] = {q.neg[2] ? hiz.x : loz.x, q.neg[2] ? hiz.y : loz.y, q.neg[2] ? hiz.z : loz.z, q.neg[2] ? hiz.w : loz.w};
+                const float fz[4] = {q.neg[2] ? loz.x : hiz.x, q.neg[2] ? loz.y : hiz.y, q.neg[2] ? loz.z : hiz.z, q.neg[2] ? loz.w : hiz.w};
+                uint32_t rf[4] = {ch.x, ch.y, ch.z, ch.w};
+                float key[4];
+                int nh = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float tn = fmaxf(fmaxf(__builtin_fmaf(nx[j], q.inv[0], q.cn[0]), __builtin_fmaf(ny[j], q.inv[1], q.cn[1])),
+                                           fmaxf(__builtin_fmaf(nz[j], q.inv[2], q.cn[2]), tmin32));
+                    const float tf = fminf(fminf(__builtin_fmaf(fx[j], q.inv[0], q.cf[0]), __builtin_fmaf(fy[j], q.inv[1], q.cf[1])),
+                                           fminf(__builtin_fmaf(fz[j], q.inv[2], q.cf[2]), best32));
+                    const bool hit = (tn <= tf) && (rf[j] != RT_REF_NONE);
+                    key[j] = hit ? tn : __builtin_inff();
+                    nh += hit ? 1 : 0;
+                    if (COUNT) nn += rf[j] != RT_REF_NONE ? 1u : 0u;
+                }
+                if (nh > 0) {
+                    // ascending by entry distance; misses (+inf) sink to the end
+                    order2(key[0], rf[0], key[1], rf[1]);
+                    order2(key[2], rf[2], key[3], rf[3]);
+                    order2(key[0], rf[0], key[2], rf[2]);
+                    order2(key[1], rf[1], key[3], rf[3]);
+                    order2(key[1], rf[1], key[2], rf[2]);
+                    if (nh > 3) st.push(rf[3], key[3]);
+                    if (nh > 2) st.push(rf[2], key[2]);
+                    if (nh > 1) st.push(rf[1], key[1]);
+                    cur = rf[0];
                     pop = false;
-                } else if (hl) { cur = wn.left; pop = false; }
-                else if (hr) { cur = wn.right; pop = false; }
-            } else if (kind == RT_REF_TRI) {
+                }
+            } else if (PRIM == RT_REF_TRI || (PRIM == 0 && kind == RT_REF_TRI)) {
                 const DTri* tp = S.tris + idx;
                 if (COUNT) ++np;
                 double t, u, v;
                 if (tri_test(d3p(tp->v0), d3p(tp->v1), d3p(tp->v2), r, tmin, best_t, t, u, v)) { best_t = t; best_ref = cur; best32 = f32_round_up(t); }
-            } else if (kind == RT_REF_SPHERE) {
+            } else if (PRIM == RT_REF_SPHERE || (PRIM == 0 && kind == RT_REF_SPHERE)) {
                 const DSphere s = S.spheres[idx];
                 if (COUNT) ++np;
                 double t;
@@ -174,16 +234,16 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh_closest_hit_kernel(DScene S, u
             }
             if (pop) {
                 for (;;) {
-                    if (sp == 0) {
+                    if (st.sp == 0) {
                         out_t[ray_slot] = best_ref == RT_REF_NONE ? D_INF : best_t;
                         out_prim[ray_slot] = best_ref;
                         active = false;
                         break;
                     }
-                    --sp;
-                    const uint2 e = stk[sp * FAST_BLOCK];
-                    // the deferred child's box was entered at e.y; closed-interval primitives may still
-                    // tie at exactly best_t, so only strictly farther subtrees are dropped
+                    const uint2 e = st.pop();
+                    // e.y is a lower bound of the distance at which the deferred subtree is entered;
+                    // closed-interval primitives may still tie at exactly best_t, so only strictly
+                    // farther subtrees are dropped
                     if (!(__uint_as_float(e.y) > best32)) { cur = e.x; break; }
                 }
             }

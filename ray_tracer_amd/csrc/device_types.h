@@ -67,6 +67,15 @@ struct alignas(16) WNode {     // 64 B
     uint32_t _pad;
 };
 
+// 4-wide node of the primitive-BVH kernel: two levels of the binary tree collapsed into one
+// 128-byte record (one cache line), boxes rounded outward to f32, structure-of-arrays per axis.
+struct alignas(128) QNode {
+    float lo[3][4];            // [axis][child] box minimum
+    float hi[3][4];            // [axis][child] box maximum
+    uint32_t child[4];         // RT_REF_NODE|q-index, a primitive reference, or RT_REF_NONE (empty slot)
+    uint32_t _pad[4];
+};
+
 struct DList { uint32_t first, count; };
 
 struct alignas(8) DXform {     // hittable.rs:61-65 / 97-102
@@ -105,6 +114,7 @@ struct DLight { uint32_t kind; uint32_t index; }; // RT_REF_SPHERE / RT_REF_QUAD
 struct DScene {
     const DNode* nodes;
     const WNode* wnodes;
+    const QNode* qnodes;
     const DSphere* spheres;
     const DQuad* quads;
     const DTri* tris;

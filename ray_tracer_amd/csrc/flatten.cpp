@@ -495,6 +495,51 @@ struct Flattener {
         return RT_OK;
     }
 
+    // Collapses two levels of the binary tree under wide node `idx` into one 4-wide node.
+    // Children keep the reference's left-to-right order; which of them is entered first is decided
+    // per ray at run time.  Returns the q-index.  `depth_out` = stack entries a traversal below needs.
+    uint32_t build_qnode(uint32_t idx, int32_t& need_out) {
+        const uint32_t me = (uint32_t)f.qnodes.size();
+        f.qnodes.emplace_back();
+        uint32_t refs[4];
+        float boxes[4][6];
+        int n = 0;
+        auto add = [&](uint32_t ref, const float* b) { refs[n] = ref; for (int k = 0; k < 6; ++k) boxes[n][k] = b[k]; ++n; };
+        auto expand = [&](uint32_t ref, const float* b) {
+            if (RT_REF_KIND(ref) == RT_REF_NODE) {
+                const WNode& c = f.wnodes[RT_REF_INDEX(ref)];
+                add(c.left, c.lb);
+                if (!(c.meta & 2u)) add(c.right, c.rb);
+            } else add(ref, b);
+        };
+        {
+            const WNode w = f.wnodes[idx];
+            expand(w.left, w.lb);
+            if (!(w.meta & 2u)) expand(w.right, w.rb);
+        }
+        int32_t deepest = 0;
+        uint32_t out_refs[4] = {RT_REF_NONE, RT_REF_NONE, RT_REF_NONE, RT_REF_NONE};
+        for (int j = 0; j < n; ++j) {
+            if (RT_REF_KIND(refs[j]) == RT_REF_NODE) {
+                int32_t nd = 0;
+                out_refs[j] = make_ref(RT_REF_NODE, build_qnode(RT_REF_INDEX(refs[j]), nd));
+                deepest = std::max(deepest, nd);
+            } else out_refs[j] = refs[j];
+        }
+        QNode& q = f.qnodes[me];
+        for (int j = 0; j < 4; ++j) {
+            q.child[j] = out_refs[j];
+            q._pad[j] = 0;
+            for (int a = 0; a < 3; ++a) {
+                // an empty slot gets an inverted box, which no ray enters
+                q.lo[a][j] = j < n ? boxes[j][2 * a] : std::numeric_limits<float>::infinity();
+                q.hi[a][j] = j < n ? boxes[j][2 * a + 1] : -std::numeric_limits<float>::infinity();
+            }
+        }
+        need_out = (n - 1) + deepest; // up to n-1 siblings stay on the stack while one child is traversed
+        return me;
+    }
+
     // Stack entries a traversal starting at `ref` can need.
     int32_t need(uint32_t ref) {
         uint32_t kind = RT_REF_KIND(ref), idx = RT_REF_INDEX(ref);
@@ -577,8 +622,10 @@ struct Flattener {
             if (RT_REF_KIND(r) == RT_REF_LIST && f.lists[RT_REF_INDEX(r)].count == 1) r = f.list_items[f.lists[RT_REF_INDEX(r)].first];
             auto it = bvh_prim_only.find(r);
             if (RT_REF_KIND(r) == RT_REF_NODE && it != bvh_prim_only.end() && it->second) {
-                f.fast_root = r;
-                f.fast_stack = (uint32_t)need(r) + 1;
+                int32_t nd = 0;
+                f.qnodes.reserve(f.nodes.size() / 2 + 1);
+                f.fast_root = make_ref(RT_REF_NODE, build_qnode(RT_REF_INDEX(r), nd));
+                f.fast_stack = (uint32_t)nd + 1;
             }
         }
         f.max_stack = (uint32_t)need(f.world) + 1;

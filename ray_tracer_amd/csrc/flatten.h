@@ -15,6 +15,7 @@ struct Box { // aabb.rs:10-14 as xmin xmax ymin ymax zmin zmax
 struct FlatScene {
     std::vector<DNode> nodes;
     std::vector<WNode> wnodes;
+    std::vector<QNode> qnodes;        // 4-wide collapse of the BVH at fast_root (empty otherwise)
     std::vector<DSphere> spheres;
     std::vector<DQuad> quads;
     std::vector<DTri> tris;

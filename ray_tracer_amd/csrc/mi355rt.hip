@@ -296,6 +296,8 @@ struct rt_scene {
     int grid_blocks = 0;
     int fast_grid_blocks = 0;
     size_t fast_lds = 0;
+    uint2* fast_spill = nullptr; // HBM overflow of the per-lane stacks: [entry][thread]
+    int fast_prim = 0;           // leaf kind of the primitive BVH when uniform, else 0
     float fast_extent = 0.0f; // largest |coordinate| of the world box (error bound of the f32 slab test)
     // render workspace
     PathState ps{};
@@ -339,13 +341,29 @@ int pick_grid(rt_scene* s) {
     per_cu = std::max(1, std::min(per_cu, per_cu2));
     s->grid_blocks = prop.multiProcessorCount * per_cu;
     if (s->flat.fast_root != RT_REF_NONE) {
-        s->fast_lds = (size_t)s->flat.fast_stack * FAST_BLOCK * sizeof(uint2);
+        s->fast_lds = 0;
         double ext = 0.0;
         for (double v : s->flat.world_bounds.b) ext = std::max(ext, std::fabs(v));
         s->fast_extent = (float)(ext * 1.0000001);
+        const bool tr = !s->flat.tris.empty(), sp = !s->flat.spheres.empty(), qd = !s->flat.quads.empty();
+        s->fast_prim = (tr && !sp && !qd) ? (int)RT_REF_TRI : ((sp && !tr && !qd) ? (int)RT_REF_SPHERE : 0);
         int fast_per_cu = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fast_per_cu, bvh_closest_hit_kernel<false>, FAST_BLOCK, s->fast_lds));
+        if (s->fast_prim == (int)RT_REF_TRI)
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fast_per_cu, bvh4_closest_hit_kernel<RT_REF_TRI, false>, FAST_BLOCK, 0));
+        else if (s->fast_prim == (int)RT_REF_SPHERE)
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fast_per_cu, bvh4_closest_hit_kernel<RT_REF_SPHERE, false>, FAST_BLOCK, 0));
+        else
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fast_per_cu, bvh4_closest_hit_kernel<0, false>, FAST_BLOCK, 0));
         s->fast_grid_blocks = prop.multiProcessorCount * std::max(1, fast_per_cu);
+        {
+            size_t entries = (size_t)std::max<uint32_t>(s->flat.fast_stack, 1u);
+            size_t bytes = entries * (size_t)s->fast_grid_blocks * FAST_BLOCK * sizeof(uint2);
+            void* p = nullptr;
+            HIP_TRY(hipMalloc(&p, bytes));
+            s->allocs.push_back(p);
+            s->device_bytes += bytes;
+            s->fast_spill = static_cast<uint2*>(p);
+        }
     }
     return RT_OK;
 }
@@ -353,7 +371,7 @@ int pick_grid(rt_scene* s) {
 void fill_host_dscene(rt_scene* s) {
     FlatScene& f = s->flat;
     DScene& d = s->dev;
-    d.nodes = f.nodes.data(); d.wnodes = f.wnodes.data(); d.spheres = f.spheres.data(); d.quads = f.quads.data(); d.tris = f.tris.data();
+    d.nodes = f.nodes.data(); d.wnodes = f.wnodes.data(); d.qnodes = f.qnodes.data(); d.spheres = f.spheres.data(); d.quads = f.quads.data(); d.tris = f.tris.data();
     d.tri_aux = f.tri_aux.data(); d.lists = f.lists.data(); d.list_items = f.list_items.data(); d.xforms = f.xforms.data();
     d.media = f.media.data(); d.materials = f.materials.data(); d.textures = f.textures.data(); d.images = f.images.data();
     d.image_bytes = f.image_bytes.data(); d.perlins = f.perlins.data(); d.lights = f.lights.data();
@@ -366,6 +384,7 @@ int upload_scene(rt_scene* s) {
     int rc;
     if ((rc = upload(s, f.nodes, &d.nodes))) return rc;
     if ((rc = upload(s, f.wnodes, &d.wnodes))) return rc;
+    if ((rc = upload(s, f.qnodes, &d.qnodes))) return rc;
     if ((rc = upload(s, f.spheres, &d.spheres))) return rc;
     if ((rc = upload(s, f.quads, &d.quads))) return rc;
     if ((rc = upload(s, f.tris, &d.tris))) return rc;
@@ -440,12 +459,20 @@ int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit
         // the world is one BVH over primitives: dedicated traversal kernel + one pass that completes the records
         int fblocks = (int)std::min<uint64_t>((uint64_t)s->fast_grid_blocks, (waves + (FAST_BLOCK / 64) - 1) / (FAST_BLOCK / 64));
         RayQueue rq{nullptr, nullptr};
-        if (count)
-            hipLaunchKernelGGL(bvh_closest_hit_kernel<true>, dim3(fblocks), dim3(FAST_BLOCK), s->fast_lds, st, s->dev, s->flat.fast_root, *rays,
-                               (unsigned long long)n, rq, 0.001, s->fast_extent, hits->t, hits->prim, s->d_counters + C_WORK, s->d_counters + C_NODES);
-        else
-            hipLaunchKernelGGL(bvh_closest_hit_kernel<false>, dim3(fblocks), dim3(FAST_BLOCK), s->fast_lds, st, s->dev, s->flat.fast_root, *rays,
-                               (unsigned long long)n, rq, 0.001, s->fast_extent, hits->t, hits->prim, s->d_counters + C_WORK, s->d_counters + C_NODES);
+        auto flaunch = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, dim3(fblocks), dim3(FAST_BLOCK), 0, st, s->dev, s->flat.fast_root, *rays, (unsigned long long)n, rq, 0.001,
+                               s->fast_extent, hits->t, hits->prim, s->d_counters + C_WORK, s->d_counters + C_NODES, s->fast_spill);
+        };
+        const int pk = s->fast_prim;
+        if (count) {
+            if (pk == (int)RT_REF_TRI) flaunch(bvh4_closest_hit_kernel<RT_REF_TRI, true>);
+            else if (pk == (int)RT_REF_SPHERE) flaunch(bvh4_closest_hit_kernel<RT_REF_SPHERE, true>);
+            else flaunch(bvh4_closest_hit_kernel<0, true>);
+        } else {
+            if (pk == (int)RT_REF_TRI) flaunch(bvh4_closest_hit_kernel<RT_REF_TRI, false>);
+            else if (pk == (int)RT_REF_SPHERE) flaunch(bvh4_closest_hit_kernel<RT_REF_SPHERE, false>);
+            else flaunch(bvh4_closest_hit_kernel<0, false>);
+        }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(s->ev_hit1, st));
         if (hits->u || hits->v || hits->front_face || hits->mat || hits->nx || hits->ny || hits->nz || hits->px || hits->py || hits->pz)
