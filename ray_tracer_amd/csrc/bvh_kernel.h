@@ -22,6 +22,7 @@ namespace rt {
 
 constexpr int FAST_BLOCK = 256;
 constexpr int REFILL_THRESHOLD = 40; // refill when fewer lanes than this are still traversing
+constexpr int LEAF_VOTE = 24;        // lanes that must stand on a primitive before the wave runs the intersector
 
 // Conservative f32 slab test of the fast kernel.  For one axis the entry / exit parameters of the
 // slab [b0, b1] are  t = b * inv + c  with c = -(o * inv)  (one fused multiply-add per plane; the
@@ -80,32 +81,41 @@ struct RayQueue {              // optional indirection: ray i of the launch is p
 };
 
 constexpr int LDS_STACK = 8;   // stack entries per lane held in LDS (power of two); deeper ones spill to HBM
+constexpr int FAST_WAVES = FAST_BLOCK / 64;
+constexpr uint32_t NO_NODE = 0xFFFFFFFFu;
 
 // Per-lane traversal stack: the newest LDS_STACK entries live in LDS ([slot][thread], 8 bytes each),
 // older ones in a per-thread column of `spill` (HBM, [entry][thread], coalesced across the wave).
+// The LDS array is indexed directly (never through a pointer kept in a struct) so every access
+// is compiled as a ds_ instruction rather than a flat one.
 struct LaneStack {
-    uint2* lds;                // this lane's column: slot s at lds[s * FAST_BLOCK]
     uint2* spill;              // this lane's column: entry k at spill[k * spill_stride]
     size_t spill_stride;
     int sp;                    // entries on the stack
     int base;                  // oldest entry still in LDS
-    RT_DEV void reset() { sp = 0; base = 0; }
-    RT_DEV void push(uint32_t ref, float near_t) {
-        if (sp - base == LDS_STACK) {
-            spill[(size_t)base * spill_stride] = lds[(base & (LDS_STACK - 1)) * FAST_BLOCK];
-            ++base;
-        }
-        uint2 e;
-        e.x = ref; e.y = __float_as_uint(near_t);
-        lds[(sp & (LDS_STACK - 1)) * FAST_BLOCK] = e;
-        ++sp;
-    }
-    RT_DEV uint2 pop() { // precondition: sp > 0
-        --sp;
-        if (sp < base) { base = sp; return spill[(size_t)sp * spill_stride]; }
-        return lds[(sp & (LDS_STACK - 1)) * FAST_BLOCK];
-    }
 };
+#define RT_STACK_SLOT(k) s_fast_stack[((k) & (LDS_STACK - 1)) * FAST_BLOCK + threadIdx.x]
+#define RT_STACK_RESET(st) do { (st).sp = 0; (st).base = 0; } while (0)
+#define RT_STACK_PUSH(st, ref, near_t)                                                        \
+    do {                                                                                      \
+        if ((st).sp - (st).base == LDS_STACK) {                                               \
+            (st).spill[(size_t)(st).base * (st).spill_stride] = RT_STACK_SLOT((st).base);     \
+            ++(st).base;                                                                      \
+        }                                                                                     \
+        uint2 e_;                                                                             \
+        e_.x = (ref); e_.y = __float_as_uint(near_t);                                         \
+        RT_STACK_SLOT((st).sp) = e_;                                                          \
+        ++(st).sp;                                                                            \
+    } while (0)
+// The LDS slot is read unconditionally and overridden by the spilled entry when there is one: a
+// conditional choice between the two loads makes hipcc (ROCm 7.2) merge them into one load through
+// a generic pointer, which its gfx950 backend then fails to select.
+#define RT_STACK_POP(st, out)                                                                 \
+    do {                                                                                      \
+        --(st).sp;                                                                            \
+        (out) = RT_STACK_SLOT((st).sp);                                                       \
+        if ((st).sp < (st).base) { (st).base = (st).sp; (out) = (st).spill[(size_t)(st).sp * (st).spill_stride]; } \
+    } while (0)
 
 RT_DEV void order2(float& ka, uint32_t& ra, float& kb, uint32_t& rb) { // ascending by key
     const bool sw = kb < ka;
@@ -114,22 +124,27 @@ RT_DEV void order2(float& ka, uint32_t& ra, float& kb, uint32_t& rb) { // ascend
     ka = k0; kb = k1; ra = r0; rb = r1;
 }
 
+// Node fetch: each lane reads its own 128-byte node with seven 16-byte loads.  A cooperative
+// variant (eight lanes fetch one node's line into LDS with global_load_lds, then ds_read_b128)
+// was measured slower on MI355X: the texture addresser's cost follows the number of load
+// wave-instructions, not the number of distinct lines, so it saved nothing and cost occupancy.
+
 // PRIM: RT_REF_TRI / RT_REF_SPHERE / RT_REF_QUAD when every leaf has that kind, 0 for mixed leaves.
 template <int PRIM, bool COUNT>
 __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, uint32_t root, rt_ray_batch rays,
-                                                                       unsigned long long n_in, RayQueue rq, double tmin_default,
+                                                                       unsigned long long n_in, RayQueue rq, uint32_t opt, double tmin_default,
                                                                        float scene_extent, double* out_t, uint32_t* out_prim,
                                                                        unsigned long long* work_counter,
                                                                        unsigned long long* stat_counters, uint2* spill) {
     __shared__ uint2 s_fast_stack[LDS_STACK * FAST_BLOCK];
     LaneStack st;
-    st.lds = s_fast_stack + threadIdx.x;
     st.spill_stride = (size_t)gridDim.x * FAST_BLOCK;
     st.spill = spill + (size_t)blockIdx.x * FAST_BLOCK + threadIdx.x;
-    st.reset();
+    RT_STACK_RESET(st);
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lane_below = (1ull << lane) - 1ull;
     const unsigned long long n = rq.count ? *rq.count : n_in;
+    const char* const qbase = reinterpret_cast<const char*>(S.qnodes);
 
     bool active = false;
     bool more = true; // wave-uniform: the counter may still hold rays
@@ -140,8 +155,11 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, 
     uint32_t best_ref = RT_REF_NONE, cur = 0;
     unsigned long long ray_slot = 0;
     uint32_t nn = 0, np = 0;
+    // wave-level occupancy diagnostics (COUNT builds only): how many lanes take part in each phase
+    uint32_t d_iters = 0, d_node_lanes = 0, d_tri_phases = 0, d_tri_lanes = 0, d_pop_iters = 0, d_pop_lanes = 0, d_rounds = 0, d_run_lanes = 0;
 
     for (;;) {
+        if (COUNT) ++d_rounds;
         if (more) {
             const unsigned long long idle = __ballot(!active);
             if (idle) {
@@ -159,15 +177,16 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, 
                         r.ox = rays.ox[i]; r.oy = rays.oy[i]; r.oz = rays.oz[i];
                         r.dx = rays.dx[i]; r.dy = rays.dy[i]; r.dz = rays.dz[i];
                         make_ray32(r, scene_extent, q);
-                        time = rays.time ? rays.time[i] : 0.0;
-                        tmin = rays.tmin ? rays.tmin[i] : tmin_default;
-                        best_t = rays.tmax ? rays.tmax[i] : D_INF;
+                        // which optional arrays exist is decided on the host (opt bits 0/1/2 = time/tmin/tmax)
+                        time = (opt & 1u) ? rays.time[i] : 0.0;
+                        tmin = (opt & 2u) ? rays.tmin[i] : tmin_default;
+                        best_t = (opt & 4u) ? rays.tmax[i] : D_INF;
                         tmin32 = f32_round_down(tmin);
                         best32 = f32_round_up(best_t);
                         best_ref = RT_REF_NONE;
                         ray_slot = i;
                         cur = root;
-                        st.reset();
+                        RT_STACK_RESET(st);
                         active = true;
                     }
                 }
@@ -176,13 +195,23 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, 
         }
         if (!__any(active)) break;
 
-        while (active) {
-            const uint32_t kind = cur >> 28, idx = cur & 0x0FFFFFFFu;
-            bool pop = true;
-            if (kind == RT_REF_NODE) {
-                const float4* qp = reinterpret_cast<const float4*>(S.qnodes + idx);
-                const float4 lox = qp[0], loy = qp[1], loz = qp[2], hix = qp[3], hiy = qp[4], hiz = qp[5];
-                const uint4 ch = *reinterpret_cast<const uint4*>(qp + 6);
+        // Wave-uniform loop: every lane keeps executing (a finished lane still serves as a helper of
+        // the cooperative fetch) until the wave is empty or enough lanes are idle to refill.
+        for (;;) {
+            // One iteration = (1) lanes standing on a node take a node step, (2) lanes standing on a
+            // primitive test it once enough of the wave stands on one (LEAF_VOTE lanes, or every
+            // lane still running), (3) lanes whose node missed or whose primitive was tested pop.
+            // Holding primitive tests back until a quorum is reached keeps the f64 intersector from
+            // running with a handful of lanes while the rest of the wave waits.
+            const bool at_node = active && (cur >> 28) == RT_REF_NODE;
+            if (COUNT) { ++d_iters; d_run_lanes += __popcll(__ballot(active)); d_node_lanes += __popcll(__ballot(at_node)); }
+            bool pop = false;
+            if (at_node) {
+                const float4* row = reinterpret_cast<const float4*>(qbase + (size_t)(cur & 0x0FFFFFFFu) * sizeof(QNode));
+                const float4 lox = row[0], loy = row[1], loz = row[2];
+                const float4 hix = row[3], hiy = row[4], hiz = row[5];
+                const float4 chf = row[6];
+                const uint4 ch = make_uint4(__float_as_uint(chf.x), __float_as_uint(chf.y), __float_as_uint(chf.z), __float_as_uint(chf.w));
                 const float nx[4] = {q.neg[0] ? hix.x : lox.x, q.neg[0] ? hix.y : lox.y, q.neg[0] ? hix.z : lox.z, q.neg[0] ? hix.w : lox.w};
                 const float fx[4] = {q.neg[0] ? lox.x : hix.x, q.neg[0] ? lox.y : hix.y, q.neg[0] ? lox.z : hix.z, q.neg[0] ? lox.w : hix.w};
                 const float ny[4] = {q.neg[1] ? hiy.x : loy.x, q.neg[1] ? hiy.y : loy.y, q.neg[1] ? hiy.z : loy.z, q.neg[1] ? hiy.w : loy.w};
@@ -210,28 +239,42 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, 
                     order2(key[0], rf[0], key[2], rf[2]);
                     order2(key[1], rf[1], key[3], rf[3]);
                     order2(key[1], rf[1], key[2], rf[2]);
-                    if (nh > 3) st.push(rf[3], key[3]);
-                    if (nh > 2) st.push(rf[2], key[2]);
-                    if (nh > 1) st.push(rf[1], key[1]);
+                    if (nh > 3) RT_STACK_PUSH(st, rf[3], key[3]);
+                    if (nh > 2) RT_STACK_PUSH(st, rf[2], key[2]);
+                    if (nh > 1) RT_STACK_PUSH(st, rf[1], key[1]);
                     cur = rf[0];
-                    pop = false;
+                } else {
+                    pop = true;
                 }
-            } else if (PRIM == RT_REF_TRI || (PRIM == 0 && kind == RT_REF_TRI)) {
-                const DTri* tp = S.tris + idx;
-                if (COUNT) ++np;
-                double t, u, v;
-                if (tri_test(d3p(tp->v0), d3p(tp->v1), d3p(tp->v2), r, tmin, best_t, t, u, v)) { best_t = t; best_ref = cur; best32 = f32_round_up(t); }
-            } else if (PRIM == RT_REF_SPHERE || (PRIM == 0 && kind == RT_REF_SPHERE)) {
-                const DSphere s = S.spheres[idx];
-                if (COUNT) ++np;
-                double t;
-                if (sphere_test(s, r, time, tmin, best_t, t)) { best_t = t; best_ref = cur; best32 = f32_round_up(t); }
-            } else { // RT_REF_QUAD
-                const DQuad* qd = S.quads + idx;
-                if (COUNT) ++np;
-                double t, al, be;
-                if (quad_test(*qd, r, tmin, best_t, t, al, be)) { best_t = t; best_ref = cur; best32 = f32_round_up(t); }
             }
+            {
+                const bool at_leaf = active && !pop && (cur >> 28) != RT_REF_NODE;
+                const unsigned long long leaf_mask = __ballot(at_leaf);
+                const unsigned long long run_mask = __ballot(active);
+                const bool quorum = __popcll(leaf_mask) >= LEAF_VOTE || leaf_mask == run_mask;
+                if (COUNT && quorum && leaf_mask) { ++d_tri_phases; d_tri_lanes += __popcll(leaf_mask); }
+                if (at_leaf && quorum) {
+                    const uint32_t kind = cur >> 28, idx = cur & 0x0FFFFFFFu;
+                    if (PRIM == RT_REF_TRI || (PRIM == 0 && kind == RT_REF_TRI)) {
+                        const DTri* tp = S.tris + idx;
+                        if (COUNT) ++np;
+                        double t, u, v;
+                        if (tri_test(d3p(tp->v0), d3p(tp->v1), d3p(tp->v2), r, tmin, best_t, t, u, v)) { best_t = t; best_ref = cur; best32 = f32_round_up(t); }
+                    } else if (PRIM == RT_REF_SPHERE || (PRIM == 0 && kind == RT_REF_SPHERE)) {
+                        const DSphere* sph = S.spheres + idx;
+                        if (COUNT) ++np;
+                        double t;
+                        if (sphere_test(*sph, r, time, tmin, best_t, t)) { best_t = t; best_ref = cur; best32 = f32_round_up(t); }
+                    } else { // RT_REF_QUAD
+                        const DQuad* qd = S.quads + idx;
+                        if (COUNT) ++np;
+                        double t, al, be;
+                        if (quad_test(*qd, r, tmin, best_t, t, al, be)) { best_t = t; best_ref = cur; best32 = f32_round_up(t); }
+                    }
+                    pop = true;
+                }
+            }
+            if (COUNT) { const unsigned long long pm = __ballot(pop); if (pm) { ++d_pop_iters; d_pop_lanes += __popcll(pm); } }
             if (pop) {
                 for (;;) {
                     if (st.sp == 0) {
@@ -240,19 +283,31 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, 
                         active = false;
                         break;
                     }
-                    const uint2 e = st.pop();
+                    uint2 e;
+                    RT_STACK_POP(st, e);
                     // e.y is a lower bound of the distance at which the deferred subtree is entered;
                     // closed-interval primitives may still tie at exactly best_t, so only strictly
                     // farther subtrees are dropped
                     if (!(__uint_as_float(e.y) > best32)) { cur = e.x; break; }
                 }
             }
-            if (more && __popcll(__ballot(true)) < REFILL_THRESHOLD) break;
+            const int running = __popcll(__ballot(active));
+            if (running == 0 || (more && running < REFILL_THRESHOLD)) break;
         }
     }
     if (COUNT) {
         atomicAdd(&stat_counters[0], (unsigned long long)nn);
         atomicAdd(&stat_counters[1], (unsigned long long)np);
+        if (lane == 0) { // per-wave values: the ballots above are wave-uniform
+            atomicAdd(&stat_counters[4], (unsigned long long)d_iters);
+            atomicAdd(&stat_counters[5], (unsigned long long)d_node_lanes);
+            atomicAdd(&stat_counters[6], (unsigned long long)d_tri_phases);
+            atomicAdd(&stat_counters[7], (unsigned long long)d_tri_lanes);
+            atomicAdd(&stat_counters[8], (unsigned long long)d_pop_iters);
+            atomicAdd(&stat_counters[9], (unsigned long long)d_pop_lanes);
+            atomicAdd(&stat_counters[10], (unsigned long long)d_rounds);
+            atomicAdd(&stat_counters[11], (unsigned long long)d_run_lanes);
+        }
     }
 }
 

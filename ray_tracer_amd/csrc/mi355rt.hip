@@ -459,8 +459,9 @@ int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit
         // the world is one BVH over primitives: dedicated traversal kernel + one pass that completes the records
         int fblocks = (int)std::min<uint64_t>((uint64_t)s->fast_grid_blocks, (waves + (FAST_BLOCK / 64) - 1) / (FAST_BLOCK / 64));
         RayQueue rq{nullptr, nullptr};
+        const uint32_t opt = (rays->time ? 1u : 0u) | (rays->tmin ? 2u : 0u) | (rays->tmax ? 4u : 0u);
         auto flaunch = [&](auto kernel) {
-            hipLaunchKernelGGL(kernel, dim3(fblocks), dim3(FAST_BLOCK), 0, st, s->dev, s->flat.fast_root, *rays, (unsigned long long)n, rq, 0.001,
+            hipLaunchKernelGGL(kernel, dim3(fblocks), dim3(FAST_BLOCK), 0, st, s->dev, s->flat.fast_root, *rays, (unsigned long long)n, rq, opt, 0.001,
                                s->fast_extent, hits->t, hits->prim, s->d_counters + C_WORK, s->d_counters + C_NODES, s->fast_spill);
         };
         const int pk = s->fast_prim;
@@ -781,6 +782,10 @@ int rt_get_counters(rt_scene* s, rt_counters* out) {
         if (s->hit_timed) { float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, s->ev_hit0, s->ev_hit1)); s->counters.ms_last_closest_hit = ms; }
         if (s->render_timed) { float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, s->ev_r0, s->ev_r1)); s->counters.ms_last_render = ms; }
         s->counters.render_rays = s->h_counters[C_RAYS];
+        if (getenv("MI355RT_DEBUG")) {
+            std::fprintf(stderr, "[mi355rt] wave diag: iters %llu node_lanes %llu tri_phases %llu tri_lanes %llu pop_iters %llu pop_lanes %llu rounds %llu run_lanes %llu\n",
+                         s->h_counters[8], s->h_counters[9], s->h_counters[10], s->h_counters[11], s->h_counters[12], s->h_counters[13], s->h_counters[14], s->h_counters[15]);
+        }
     }
     *out = s->counters;
     return RT_OK;
