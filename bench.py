@@ -35,7 +35,7 @@ def main() -> None:
     ap.add_argument("--rays", type=int, default=1 << 24)
     ap.add_argument("--triangles", type=int, default=1 << 20)
     ap.add_argument("--mode", choices=["reference", "ordered"], default=os.environ.get("MI355RT_BENCH_MODE", "ordered"))
-    ap.add_argument("--cpu-sample", type=int, default=1 << 21, help="rays of the batch timed on the host cores")
+    ap.add_argument("--cpu-sample", type=int, default=1 << 23, help="rays of the batch timed on the host cores")
     ap.add_argument("--count-sample", type=int, default=1 << 16, help="rays used for the reference-order visit counts")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -138,7 +138,7 @@ def main() -> None:
         achieved = bytes_per_ray * n / (avg_ms * 1e-3) / 1e9
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": _traffic_from_env(),
-                           "kernel": "closest_hit_kernel", "kernel_ms": avg_ms,
+                           "kernel": "bvh4_closest_hit_kernel" if args.mode == "ordered" else "closest_hit_kernel", "kernel_ms": avg_ms,
                            "ref_order_nodes_per_ray": nodes_per_ray, "ref_order_prims_per_ray": prims_per_ray,
                            "alg_bytes_per_ray": bytes_per_ray, "count_sample_rays": m,
                            "actual_box_tests_per_ray": actual_nodes, "actual_prim_tests_per_ray": actual_prims,

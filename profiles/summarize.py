@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Turns the rocprofv3 outputs of one round (kernel trace + counter passes, merged back under
+gpurun_out/) into the tracked summaries under profiles/:  <tag>_kernel_stats.csv,
+<tag>_counters.csv, <tag>_summary.md and traffic.json (HBM-side bytes per launch of the dominant
+kernel, read by bench.py).  Usage: python profiles/summarize.py r1 <kernel-name-substring>"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag, kernel = sys.argv[1], sys.argv[2]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out")
+dst = os.path.join(root, "profiles")
+
+stats = glob.glob(os.path.join(src, f"{tag}_trace", "*", "*_kernel_stats.csv"))
+avg_ns = None
+if stats:
+    shutil.copy(stats[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
+    for row in csv.DictReader(open(stats[0])):
+        if kernel in row["Name"] and "false" in row["Name"]:
+            avg_ns = float(row["AverageNs"])
+
+vals = {}
+for d in (f"{tag}_pmc", f"{tag}_pmc_mem"):
+    for f in glob.glob(os.path.join(src, d, "*", "*", "*_counter_collection.csv")):
+        for row in csv.DictReader(open(f)):
+            if kernel in row["Kernel_Name"] and "false" in row["Kernel_Name"]:
+                vals.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+mean = {k: sum(v) / len(v) for k, v in vals.items()}
+with open(os.path.join(dst, f"{tag}_counters.csv"), "w") as fh:
+    fh.write("counter,mean_per_launch,launches\n")
+    for k in sorted(mean):
+        fh.write(f"{k},{mean[k]:.6g},{len(vals[k])}\n")
+
+bench = {}
+p = os.path.join(src, f"{tag}_bench.json")
+if os.path.exists(p):
+    bench = json.load(open(p))
+    shutil.copy(p, os.path.join(dst, f"{tag}_bench.json"))
+
+lines = [f"# {tag}: rocprofv3 summary for `{kernel}` (bench.py default command, one MI355X)", ""]
+if avg_ns:
+    lines.append(f"* kernel-trace average duration: **{avg_ns / 1e6:.3f} ms** per launch "
+                 f"(library HIP events in the same run: {bench.get('roofline', {}).get('kernel_ms', float('nan')):.3f} ms)")
+if mean:
+    cyc = mean.get("GRBM_GUI_ACTIVE", 0) / 8.0
+    fetch = mean.get("FETCH_SIZE", 0) * 1024 * 2  # gfx950: FETCH_SIZE tallies 128-B requests at 64 B (calibrated on a
+    write = mean.get("WRITE_SIZE", 0) * 1024      # random 128-B row gather, profiles/fetch_calib.hip: factor 2.000)
+    traffic = fetch + write
+    json.dump({"hbm_bytes_per_launch": traffic, "fetch_bytes": fetch, "write_bytes": write,
+               "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, {tag}; FETCH_SIZE doubled per the gfx950 "
+                         "calibration (profiles/fetch_calib.hip measured 1.9996)"}, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+    ms = (avg_ns or 0) / 1e6
+    lines += [
+        f"* shader clock during the kernel: {cyc / (ms * 1e-3) / 1e9:.2f} GHz (GRBM_GUI_ACTIVE / 8 / duration)" if ms else "",
+        f"* fabric-side traffic (L2 <-> Infinity Cache / HBM): {traffic / 1e9:.1f} GB per launch = "
+        f"**{traffic / (ms * 1e-3) / 1e12:.2f} TB/s**" if ms else "",
+        f"* L2 hit rate: {100 * mean.get('TCC_HIT_sum', 0) / max(1.0, mean.get('TCC_HIT_sum', 0) + mean.get('TCC_MISS_sum', 0)):.1f} % "
+        f"({mean.get('TCC_REQ_sum', 0):.3g} requests)",
+        f"* texture addresser busy: {100 * mean.get('TA_TA_BUSY_sum', 0) / max(1.0, 256 * cyc):.0f} % of 256 CUs x kernel cycles; "
+        f"L1 accesses {mean.get('TCP_TOTAL_CACHE_ACCESSES_sum', 0):.3g}",
+        f"* waves {mean.get('SQ_WAVES', 0):.0f}; wave time waiting (SQ_WAIT_ANY / SQ_WAVE_CYCLES): "
+        f"{100 * mean.get('SQ_WAIT_ANY', 0) / max(1.0, mean.get('SQ_WAVE_CYCLES', 0)):.0f} %",
+        f"* VALU lane utilisation (SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)): "
+        f"{100 * mean.get('SQ_THREAD_CYCLES_VALU', 0) / max(1.0, 64 * mean.get('SQ_ACTIVE_INST_VALU', 0)):.0f} %; "
+        f"VALU wave-instructions {mean.get('SQ_INSTS_VALU', 0):.3g}, SALU {mean.get('SQ_INSTS_SALU', 0):.3g}, "
+        f"vector loads {mean.get('SQ_INSTS_VMEM_RD', 0):.3g}, LDS {mean.get('SQ_INSTS_LDS', 0):.3g}",
+    ]
+if bench:
+    r = bench.get("roofline", {})
+    lines += ["", f"bench.py line of the same build: {bench.get('value', 0):.1f} Mrays/s, {bench.get('ms_per_step', 0):.2f} ms/step, "
+                  f"roofline.achieved {r.get('achieved', 0):.0f} GB/s (reference-order algorithmic bytes), "
+                  f"actual {r.get('achieved_actual', 0):.0f} GB/s of node/triangle gathers, cpu_baseline "
+                  f"{bench.get('cpu_baseline', {}).get('value', 0):.3f} Mrays/s on {bench.get('cpu_baseline', {}).get('cores', 0)} threads."]
+open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(l for l in lines if l is not None) + "\n")
+print(open(os.path.join(dst, f"{tag}_summary.md")).read())

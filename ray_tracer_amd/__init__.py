@@ -10,3 +10,4 @@ from .material import Dielectric, DiffuseLight, Isotropic, Lambertian, Material,
 from .scene import Scene, SceneDesc  # noqa: F401
 from .texture import CheckerTexture, ImageTexture, NoiseTexture, Perlin, RtwImage, SolidColor, Texture  # noqa: F401
 from .vec3 import Color, Point3, Vec3, cross, dot, unit_vector  # noqa: F401
+from . import parallel  # noqa: F401,E402
