@@ -124,19 +124,29 @@ RT_DEV void order2(float& ka, uint32_t& ra, float& kb, uint32_t& rb) { // ascend
     ka = k0; kb = k1; ra = r0; rb = r1;
 }
 
-// Node fetch: each lane reads its own 128-byte node with seven 16-byte loads.  A cooperative
-// variant (eight lanes fetch one node's line into LDS with global_load_lds, then ds_read_b128)
-// was measured slower on MI355X: the texture addresser's cost follows the number of load
-// wave-instructions, not the number of distinct lines, so it saved nothing and cost occupancy.
+// Node fetch.  A lane that reads its own 128-byte node issues eight 16-byte requests, and the
+// vector L1 of a CU handles divergent requests at a fixed rate per (lane, request) no matter that
+// they fall into one line: measured on MI355X, per-lane pointer chasing delivers 47 G rows/s with
+// seven requests per row but 145 G rows/s when the eight lanes of a group read the eight 16-byte
+// pieces of ONE row in a single instruction (one line request) and the rows are handed to their
+// owners through LDS (profiles/gather_probe.hip).  COOP selects that cooperative fetch: eight load
+// instructions bring the 64 nodes of the wave into a per-wave 8 KB staging area, each lane then
+// reads its own node back.  Chunk c of row r is kept at position c ^ (r & 7), which makes both the
+// row-wise writes and the lane-wise reads bank-conflict free without padding.
+constexpr int STAGE_CHUNKS = 8; // 16-byte chunks per staged row (one QNode)
+#define RT_STAGE(row, chunk) s_stage[((wave_in_block * 64 + (row)) * STAGE_CHUNKS) + ((chunk) ^ ((row) & 7))]
 
 // PRIM: RT_REF_TRI / RT_REF_SPHERE / RT_REF_QUAD when every leaf has that kind, 0 for mixed leaves.
-template <int PRIM, bool COUNT>
+template <int PRIM, bool COUNT, bool COOP>
 __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, uint32_t root, rt_ray_batch rays,
                                                                        unsigned long long n_in, RayQueue rq, uint32_t opt, double tmin_default,
                                                                        float scene_extent, double* out_t, uint32_t* out_prim,
                                                                        unsigned long long* work_counter,
-                                                                       unsigned long long* stat_counters, uint2* spill) {
+                                                                       unsigned long long* stat_counters, uint2* spill, int refill_threshold,
+                                                                       int leaf_vote, int chunk) {
     __shared__ uint2 s_fast_stack[LDS_STACK * FAST_BLOCK];
+    __shared__ float4 s_stage[COOP ? FAST_BLOCK * STAGE_CHUNKS : 1];
+    const uint32_t wave_in_block = threadIdx.x >> 6;
     LaneStack st;
     st.spill_stride = (size_t)gridDim.x * FAST_BLOCK;
     st.spill = spill + (size_t)blockIdx.x * FAST_BLOCK + threadIdx.x;
@@ -148,6 +158,7 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, 
 
     bool active = false;
     bool more = true; // wave-uniform: the counter may still hold rays
+    unsigned long long wave_next = 0, wave_end = 0; // wave-uniform: the part of the batch this wave still owns
     RayD r;
     Ray32 q;
     float tmin32 = 0.0f, best32 = 0.0f;
@@ -163,16 +174,24 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, 
         if (more) {
             const unsigned long long idle = __ballot(!active);
             if (idle) {
-                const int nidle = __popcll(idle);
-                const int leader = __ffsll((long long)idle) - 1;
-                unsigned long long base = 0;
-                if ((int)lane == leader) base = atomicAdd(work_counter, (unsigned long long)nidle);
-                const uint32_t blo = (uint32_t)__shfl((int)(uint32_t)base, leader);
-                const uint32_t bhi = (uint32_t)__shfl((int)(uint32_t)(base >> 32), leader);
-                base = ((unsigned long long)bhi << 32) | blo;
+                // The wave owns a private range [wave_next, wave_end) of the batch and takes a new one of
+                // `chunk` rays from the global counter only when it is used up: one device-wide atomic
+                // per chunk instead of one per refill (all waves increment the same word, and MI355X
+                // serves same-address atomics at roughly 10 ns each).
+                if (wave_next >= wave_end) {
+                    const int leader = __ffsll((long long)idle) - 1;
+                    unsigned long long base = 0;
+                    if ((int)lane == leader) base = atomicAdd(work_counter, (unsigned long long)chunk);
+                    const uint32_t blo = (uint32_t)__shfl((int)(uint32_t)base, leader);
+                    const uint32_t bhi = (uint32_t)__shfl((int)(uint32_t)(base >> 32), leader);
+                    wave_next = ((unsigned long long)bhi << 32) | blo;
+                    wave_end = wave_next + (unsigned long long)chunk;
+                    if (wave_end > n) wave_end = n;
+                    if (wave_next >= n) { wave_next = wave_end = n; more = false; }
+                }
                 if (!active) {
-                    const unsigned long long qi = base + (unsigned long long)__popcll(idle & lane_below);
-                    if (qi < n) {
+                    const unsigned long long qi = wave_next + (unsigned long long)__popcll(idle & lane_below);
+                    if (qi < wave_end) {
                         const unsigned long long i = rq.queue ? (unsigned long long)rq.queue[qi] : qi;
                         r.ox = rays.ox[i]; r.oy = rays.oy[i]; r.oz = rays.oz[i];
                         r.dx = rays.dx[i]; r.dy = rays.dy[i]; r.dz = rays.dz[i];
@@ -190,7 +209,8 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, 
                         active = true;
                     }
                 }
-                if (base + (unsigned long long)nidle >= n) more = false;
+                const unsigned long long left = wave_end - wave_next, want = (unsigned long long)__popcll(idle);
+                wave_next += want < left ? want : left;
             }
         }
         if (!__any(active)) break;
@@ -206,11 +226,32 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, 
             const bool at_node = active && (cur >> 28) == RT_REF_NODE;
             if (COUNT) { ++d_iters; d_run_lanes += __popcll(__ballot(active)); d_node_lanes += __popcll(__ballot(at_node)); }
             bool pop = false;
+            if (COOP) {
+                // lanes without a node ask for the root's row, which stays in cache
+                const uint32_t my_row = at_node ? (cur & 0x0FFFFFFFu) : (root & 0x0FFFFFFFu);
+                const uint32_t sub = lane & 7u, grp = lane & ~7u;
+                float4 piece[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const uint32_t rrow = (uint32_t)__shfl((int)my_row, (int)(grp + k));
+                    piece[k] = reinterpret_cast<const float4*>(qbase + (size_t)rrow * sizeof(QNode))[sub];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) RT_STAGE(grp + k, sub) = piece[k];
+                __builtin_amdgcn_wave_barrier();
+            }
             if (at_node) {
-                const float4* row = reinterpret_cast<const float4*>(qbase + (size_t)(cur & 0x0FFFFFFFu) * sizeof(QNode));
-                const float4 lox = row[0], loy = row[1], loz = row[2];
-                const float4 hix = row[3], hiy = row[4], hiz = row[5];
-                const float4 chf = row[6];
+                float4 lox, loy, loz, hix, hiy, hiz, chf;
+                if (COOP) {
+                    lox = RT_STAGE(lane, 0); loy = RT_STAGE(lane, 1); loz = RT_STAGE(lane, 2);
+                    hix = RT_STAGE(lane, 3); hiy = RT_STAGE(lane, 4); hiz = RT_STAGE(lane, 5);
+                    chf = RT_STAGE(lane, 6);
+                } else {
+                    const float4* row = reinterpret_cast<const float4*>(qbase + (size_t)(cur & 0x0FFFFFFFu) * sizeof(QNode));
+                    lox = row[0]; loy = row[1]; loz = row[2];
+                    hix = row[3]; hiy = row[4]; hiz = row[5];
+                    chf = row[6];
+                }
                 const uint4 ch = make_uint4(__float_as_uint(chf.x), __float_as_uint(chf.y), __float_as_uint(chf.z), __float_as_uint(chf.w));
                 const float nx[4] = {q.neg[0] ? hix.x : lox.x, q.neg[0] ? hix.y : lox.y, q.neg[0] ? hix.z : lox.z, q.neg[0] ? hix.w : lox.w};
                 const float fx[4] = {q.neg[0] ? lox.x : hix.x, q.neg[0] ? lox.y : hix.y, q.neg[0] ? lox.z : hix.z, q.neg[0] ? lox.w : hix.w};
@@ -247,11 +288,12 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, 
                     pop = true;
                 }
             }
+            if (COOP) __builtin_amdgcn_wave_barrier(); // staged rows are consumed before the next fetch overwrites them
             {
                 const bool at_leaf = active && !pop && (cur >> 28) != RT_REF_NODE;
                 const unsigned long long leaf_mask = __ballot(at_leaf);
                 const unsigned long long run_mask = __ballot(active);
-                const bool quorum = __popcll(leaf_mask) >= LEAF_VOTE || leaf_mask == run_mask;
+                const bool quorum = __popcll(leaf_mask) >= leaf_vote || leaf_mask == run_mask;
                 if (COUNT && quorum && leaf_mask) { ++d_tri_phases; d_tri_lanes += __popcll(leaf_mask); }
                 if (at_leaf && quorum) {
                     const uint32_t kind = cur >> 28, idx = cur & 0x0FFFFFFFu;
@@ -292,7 +334,7 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, 
                 }
             }
             const int running = __popcll(__ballot(active));
-            if (running == 0 || (more && running < REFILL_THRESHOLD)) break;
+            if (running == 0 || (more && running < refill_threshold)) break;
         }
     }
     if (COUNT) {

@@ -540,6 +540,92 @@ struct Flattener {
         return me;
     }
 
+    // 8-wide compressed collapse (triangle leaves only).  Starting from the two children of binary node
+    // `idx`, the inner child with the largest surface area is replaced by its own children until eight
+    // slots are used or only leaves remain; a one-object span (bvh.rs:41-44) contributes its object once.
+    // Child boxes are snapped outward onto the node's 8-bit grid.  Fills cnodes[me]; returns the stack
+    // entries a traversal below this node can need.
+    struct CItem { uint32_t ref; float box[6]; };
+    static double box_area(const float* b) {
+        const double dx = (double)b[1] - b[0], dy = (double)b[3] - b[2], dz = (double)b[5] - b[4];
+        return dx * dy + dy * dz + dz * dx;
+    }
+    int children_of(uint32_t node_idx, CItem* out) const {
+        const WNode& c = f.wnodes[node_idx];
+        out[0].ref = c.left;
+        std::copy(c.lb, c.lb + 6, out[0].box);
+        if (c.meta & 2u) return 1;
+        out[1].ref = c.right;
+        std::copy(c.rb, c.rb + 6, out[1].box);
+        return 2;
+    }
+    int32_t fill_cnode(uint32_t me, uint32_t idx) {
+        CItem items[8];
+        int n = children_of(idx, items);
+        while (n < 8) {
+            int pick = -1;
+            double best = -1.0;
+            for (int j = 0; j < n; ++j)
+                if (RT_REF_KIND(items[j].ref) == RT_REF_NODE) {
+                    const double a = box_area(items[j].box);
+                    if (pick < 0 || a > best) { best = a; pick = j; }
+                }
+            if (pick < 0) break;
+            CItem sub[2];
+            const int m = children_of(RT_REF_INDEX(items[pick].ref), sub);
+            items[pick] = sub[0];
+            if (m == 2) items[n++] = sub[1];
+        }
+        CNode c{};
+        for (int a = 0; a < 3; ++a) {
+            float lo = items[0].box[2 * a], hi = items[0].box[2 * a + 1];
+            for (int j = 1; j < n; ++j) { lo = std::min(lo, items[j].box[2 * a]); hi = std::max(hi, items[j].box[2 * a + 1]); }
+            c.origin[a] = lo;
+            const double extent = (double)hi - (double)lo;
+            int e = 1; // biased exponent of the grid step, a normal float: 1..254
+            if (extent > 0.0) {
+                int ex;
+                std::frexp(extent / 255.0, &ex); // extent/255 = m * 2^ex, m in [0.5, 1): 2^ex >= extent/255
+                e = std::min(254, std::max(1, ex + 127));
+                while (e < 254 && std::ldexp(255.0, e - 127) < extent) ++e;
+            }
+            c.exp[a] = (uint8_t)e;
+            const double step = std::ldexp(1.0, e - 127);
+            for (int j = 0; j < 8; ++j) {
+                if (j >= n) { c.qlo[a][j] = 255; c.qhi[a][j] = 0; continue; }
+                const double l = (double)items[j].box[2 * a] - (double)lo, h = (double)items[j].box[2 * a + 1] - (double)lo;
+                double ql = std::floor(l / step), qh = std::ceil(h / step);
+                while (ql > 0.0 && ql * step > l) ql -= 1.0;
+                while (qh < 255.0 && qh * step < h) qh += 1.0;
+                c.qlo[a][j] = (uint8_t)std::min(255.0, std::max(0.0, ql));
+                c.qhi[a][j] = (uint8_t)std::min(255.0, std::max(0.0, qh));
+            }
+        }
+        uint32_t n_inner = 0, n_leaf = 0;
+        c.child_base = (uint32_t)f.cnodes.size();
+        c.prim_base = (uint32_t)f.ctris.size();
+        uint32_t inner_idx[8];
+        for (int j = 0; j < n; ++j) {
+            c.valid |= (uint8_t)(1u << j);
+            if (RT_REF_KIND(items[j].ref) == RT_REF_NODE) {
+                inner_idx[n_inner] = RT_REF_INDEX(items[j].ref);
+                c.meta[j] = (uint8_t)n_inner++;
+            } else {
+                const DTri& t = f.tris[RT_REF_INDEX(items[j].ref)];
+                CTri ct{};
+                std::copy(t.v0, t.v0 + 3, ct.v0); std::copy(t.v1, t.v1 + 3, ct.v1); std::copy(t.v2, t.v2 + 3, ct.v2);
+                ct.ref = items[j].ref;
+                f.ctris.push_back(ct);
+                c.meta[j] = (uint8_t)(0x80u | n_leaf++);
+            }
+        }
+        f.cnodes.resize(f.cnodes.size() + n_inner);
+        f.cnodes[me] = c;
+        int32_t deepest = 0;
+        for (uint32_t k = 0; k < n_inner; ++k) deepest = std::max(deepest, fill_cnode(c.child_base + k, inner_idx[k]));
+        return (n - 1) + deepest;
+    }
+
     // Stack entries a traversal starting at `ref` can need.
     int32_t need(uint32_t ref) {
         uint32_t kind = RT_REF_KIND(ref), idx = RT_REF_INDEX(ref);
@@ -626,6 +712,14 @@ struct Flattener {
                 f.qnodes.reserve(f.nodes.size() / 2 + 1);
                 f.fast_root = make_ref(RT_REF_NODE, build_qnode(RT_REF_INDEX(r), nd));
                 f.fast_stack = (uint32_t)nd + 1;
+                bool finite = true;
+                for (double v : f.world_bounds.b) finite = finite && std::isfinite(v);
+                if (finite && !f.tris.empty() && f.spheres.empty() && f.quads.empty()) {
+                    f.cnodes.reserve(f.nodes.size() / 3 + 8);
+                    f.ctris.reserve(f.tris.size());
+                    f.cnodes.emplace_back();
+                    f.fast8_stack = (uint32_t)fill_cnode(0, RT_REF_INDEX(r)) + 1;
+                }
             }
         }
         f.max_stack = (uint32_t)need(f.world) + 1;

@@ -22,6 +22,7 @@
 #include "flatten.h"
 #include "shade.h"
 #include "bvh_kernel.h"
+#include "bvh8_kernel.h"
 
 using namespace rt;
 
@@ -297,7 +298,11 @@ struct rt_scene {
     int fast_grid_blocks = 0;
     size_t fast_lds = 0;
     uint2* fast_spill = nullptr; // HBM overflow of the per-lane stacks: [entry][thread]
+    bool fast8 = false;          // triangle mesh: traverse the 8-wide compressed tree (cnodes / ctris)
+    int fast8_grid_blocks = 0;
+    uint2* fast8_spill = nullptr;
     int fast_prim = 0;           // leaf kind of the primitive BVH when uniform, else 0
+    bool fast_coop = true;       // cooperative (LDS-staged) node fetch in the primitive-BVH kernel
     float fast_extent = 0.0f; // largest |coordinate| of the world box (error bound of the f32 slab test)
     // render workspace
     PathState ps{};
@@ -331,6 +336,26 @@ int upload(rt_scene* s, const std::vector<T>& v, const T** out) {
     return RT_OK;
 }
 
+using FastKernel = void (*)(DScene, uint32_t, rt_ray_batch, unsigned long long, RayQueue, uint32_t, double, float, double*, uint32_t*,
+                            unsigned long long*, unsigned long long*, uint2*, int, int, int);
+template <bool COUNT, bool COOP> FastKernel fast_kernel_for(int prim) {
+    if (prim == (int)RT_REF_TRI) return bvh4_closest_hit_kernel<RT_REF_TRI, COUNT, COOP>;
+    if (prim == (int)RT_REF_SPHERE) return bvh4_closest_hit_kernel<RT_REF_SPHERE, COUNT, COOP>;
+    return bvh4_closest_hit_kernel<0, COUNT, COOP>;
+}
+FastKernel fast_kernel(int prim, bool count, bool coop) {
+    if (coop) return count ? fast_kernel_for<true, true>(prim) : fast_kernel_for<false, true>(prim);
+    return count ? fast_kernel_for<true, false>(prim) : fast_kernel_for<false, false>(prim);
+}
+int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+bool coop_setting() { // MI355RT_COOP=0 selects the per-lane node fetch (for A/B measurements)
+    const char* e = getenv("MI355RT_COOP");
+    return !(e && e[0] == '0');
+}
+
 int pick_grid(rt_scene* s) {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, s->device));
@@ -348,12 +373,9 @@ int pick_grid(rt_scene* s) {
         const bool tr = !s->flat.tris.empty(), sp = !s->flat.spheres.empty(), qd = !s->flat.quads.empty();
         s->fast_prim = (tr && !sp && !qd) ? (int)RT_REF_TRI : ((sp && !tr && !qd) ? (int)RT_REF_SPHERE : 0);
         int fast_per_cu = 0;
-        if (s->fast_prim == (int)RT_REF_TRI)
-            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fast_per_cu, bvh4_closest_hit_kernel<RT_REF_TRI, false>, FAST_BLOCK, 0));
-        else if (s->fast_prim == (int)RT_REF_SPHERE)
-            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fast_per_cu, bvh4_closest_hit_kernel<RT_REF_SPHERE, false>, FAST_BLOCK, 0));
-        else
-            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fast_per_cu, bvh4_closest_hit_kernel<0, false>, FAST_BLOCK, 0));
+        s->fast_coop = coop_setting();
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fast_per_cu, fast_kernel(s->fast_prim, false, s->fast_coop), FAST_BLOCK, 0));
+        if (getenv("MI355RT_DEBUG")) fprintf(stderr, "[mi355rt] primitive-BVH kernel: coop=%d blocks/CU=%d\n", (int)s->fast_coop, fast_per_cu);
         s->fast_grid_blocks = prop.multiProcessorCount * std::max(1, fast_per_cu);
         {
             size_t entries = (size_t)std::max<uint32_t>(s->flat.fast_stack, 1u);
@@ -364,6 +386,21 @@ int pick_grid(rt_scene* s) {
             s->device_bytes += bytes;
             s->fast_spill = static_cast<uint2*>(p);
         }
+        const char* e8 = getenv("MI355RT_BVH8"); // MI355RT_BVH8=0 keeps triangle meshes on the 4-wide kernel (A/B measurements)
+        s->fast8 = !s->flat.cnodes.empty() && !(e8 && e8[0] == '0');
+        if (s->fast8) {
+            int per_cu8 = 0;
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu8, bvh8_closest_hit_kernel<false>, FAST_BLOCK, 0));
+            if (getenv("MI355RT_DEBUG")) fprintf(stderr, "[mi355rt] compressed 8-wide kernel: blocks/CU=%d nodes=%zu\n", per_cu8, s->flat.cnodes.size());
+            s->fast8_grid_blocks = prop.multiProcessorCount * std::max(1, per_cu8);
+            size_t entries = (size_t)std::max<uint32_t>(s->flat.fast8_stack, 1u);
+            size_t bytes = entries * (size_t)s->fast8_grid_blocks * FAST_BLOCK * sizeof(uint2);
+            void* p = nullptr;
+            HIP_TRY(hipMalloc(&p, bytes));
+            s->allocs.push_back(p);
+            s->device_bytes += bytes;
+            s->fast8_spill = static_cast<uint2*>(p);
+        }
     }
     return RT_OK;
 }
@@ -371,7 +408,7 @@ int pick_grid(rt_scene* s) {
 void fill_host_dscene(rt_scene* s) {
     FlatScene& f = s->flat;
     DScene& d = s->dev;
-    d.nodes = f.nodes.data(); d.wnodes = f.wnodes.data(); d.qnodes = f.qnodes.data(); d.spheres = f.spheres.data(); d.quads = f.quads.data(); d.tris = f.tris.data();
+    d.nodes = f.nodes.data(); d.wnodes = f.wnodes.data(); d.qnodes = f.qnodes.data(); d.cnodes = f.cnodes.data(); d.ctris = f.ctris.data(); d.spheres = f.spheres.data(); d.quads = f.quads.data(); d.tris = f.tris.data();
     d.tri_aux = f.tri_aux.data(); d.lists = f.lists.data(); d.list_items = f.list_items.data(); d.xforms = f.xforms.data();
     d.media = f.media.data(); d.materials = f.materials.data(); d.textures = f.textures.data(); d.images = f.images.data();
     d.image_bytes = f.image_bytes.data(); d.perlins = f.perlins.data(); d.lights = f.lights.data();
@@ -385,6 +422,8 @@ int upload_scene(rt_scene* s) {
     if ((rc = upload(s, f.nodes, &d.nodes))) return rc;
     if ((rc = upload(s, f.wnodes, &d.wnodes))) return rc;
     if ((rc = upload(s, f.qnodes, &d.qnodes))) return rc;
+    if ((rc = upload(s, f.cnodes, &d.cnodes))) return rc;
+    if ((rc = upload(s, f.ctris, &d.ctris))) return rc;
     if ((rc = upload(s, f.spheres, &d.spheres))) return rc;
     if ((rc = upload(s, f.quads, &d.quads))) return rc;
     if ((rc = upload(s, f.tris, &d.tris))) return rc;
@@ -460,19 +499,22 @@ int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit
         int fblocks = (int)std::min<uint64_t>((uint64_t)s->fast_grid_blocks, (waves + (FAST_BLOCK / 64) - 1) / (FAST_BLOCK / 64));
         RayQueue rq{nullptr, nullptr};
         const uint32_t opt = (rays->time ? 1u : 0u) | (rays->tmin ? 2u : 0u) | (rays->tmax ? 4u : 0u);
+        // rays a wave takes from the global counter at a time: large enough to make the counter cheap, small
+        // enough that every launched wave gets several chunks
+        const uint64_t waves_launched = (uint64_t)fblocks * (FAST_BLOCK / 64);
+        const int chunk = env_int("MI355RT_CHUNK", (int)std::max<uint64_t>(16, std::min<uint64_t>(128, n / (waves_launched * 8))));
         auto flaunch = [&](auto kernel) {
             hipLaunchKernelGGL(kernel, dim3(fblocks), dim3(FAST_BLOCK), 0, st, s->dev, s->flat.fast_root, *rays, (unsigned long long)n, rq, opt, 0.001,
-                               s->fast_extent, hits->t, hits->prim, s->d_counters + C_WORK, s->d_counters + C_NODES, s->fast_spill);
+                               s->fast_extent, hits->t, hits->prim, s->d_counters + C_WORK, s->d_counters + C_NODES, s->fast_spill,
+                               env_int("MI355RT_REFILL", REFILL_THRESHOLD), env_int("MI355RT_VOTE", LEAF_VOTE), chunk);
         };
-        const int pk = s->fast_prim;
-        if (count) {
-            if (pk == (int)RT_REF_TRI) flaunch(bvh4_closest_hit_kernel<RT_REF_TRI, true>);
-            else if (pk == (int)RT_REF_SPHERE) flaunch(bvh4_closest_hit_kernel<RT_REF_SPHERE, true>);
-            else flaunch(bvh4_closest_hit_kernel<0, true>);
+        if (s->fast8) {
+            const int blocks8 = (int)std::min<uint64_t>((uint64_t)s->fast8_grid_blocks, (waves + (FAST_BLOCK / 64) - 1) / (FAST_BLOCK / 64));
+            hipLaunchKernelGGL(count ? bvh8_closest_hit_kernel<true> : bvh8_closest_hit_kernel<false>, dim3(blocks8), dim3(FAST_BLOCK), 0, st,
+                               s->dev, *rays, (unsigned long long)n, rq, opt, 0.001, s->fast_extent, hits->t, hits->prim, s->d_counters + C_WORK,
+                               s->d_counters + C_NODES, s->fast8_spill);
         } else {
-            if (pk == (int)RT_REF_TRI) flaunch(bvh4_closest_hit_kernel<RT_REF_TRI, false>);
-            else if (pk == (int)RT_REF_SPHERE) flaunch(bvh4_closest_hit_kernel<RT_REF_SPHERE, false>);
-            else flaunch(bvh4_closest_hit_kernel<0, false>);
+            flaunch(fast_kernel(s->fast_prim, count, s->fast_coop));
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(s->ev_hit1, st));
