@@ -206,6 +206,20 @@ typedef struct rt_scene_info {
 int rt_scene_get_info(const rt_scene* scene, rt_scene_info* info);
 /* Copies nodes [first, first+count) of the flattened node array. */
 int rt_scene_get_nodes(const rt_scene* scene, uint64_t first, uint64_t count, rt_bvh_node* out);
+/* The 4-wide nodes the primitive-BVH kernel traverses when the world is one BVH over primitives
+ * (two levels of bvh.rs:20-77 collapsed per node): for every child the box rounded outward to f32
+ * and, when the scene also carries the 64-byte nodes, the box decoded from their 8-bit grid.
+ * Used to check that each stored box contains the reference's box of that child. */
+typedef struct rt_wide_node {
+    uint32_t child[4];     /* RT_REF_NODE | wide index, a primitive reference, or RT_REF_NONE */
+    double   box32[4][6];  /* xmin xmax ymin ymax zmin zmax per child (f32 values) */
+    double   box8[4][6];   /* decoded 8-bit boxes; valid only when has_box8 != 0 */
+    int32_t  has_box8;
+    int32_t  _pad;
+} rt_wide_node;
+/* Number of wide nodes (0 when the scene has no primitive-only BVH world); node 0 is the root. */
+int rt_scene_wide_node_count(const rt_scene* scene, uint64_t* count);
+int rt_scene_get_wide_nodes(const rt_scene* scene, uint64_t first, uint64_t count, rt_wide_node* out);
 /* bounding_box() of an object of the description (hittable.rs:50), as 6 doubles. */
 int rt_scene_object_bounds(const rt_scene* scene, int32_t object, double out[6]);
 

@@ -1,11 +1,12 @@
 #!/bin/bash
-# Memory-pipeline counter passes (texture addresser / L1) for bench.py.  Usage: profiles/run_pmc_mem.sh <outdir>
+# Memory-side counter passes for bench.py under the current environment (one rocprofv3 run per pass).
+# Usage: profiles/run_pmc_mem.sh <outdir>
 out=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
-run() { name=$1; shift; timeout -s KILL 240 rocprofv3 --pmc "$@" --output-format csv -d "$out/$name" -- python3 bench.py --steps 2 --warmup 1 --no-cpu $BENCH_ARGS > "$out/$name.log" 2>&1 || exit 1; }
+run() { name=$1; shift; timeout -s KILL 240 rocprofv3 --pmc "$@" --output-format csv -d "$out/$name" -- python3 bench.py --steps 2 --warmup 1 --no-cpu > "$out/$name.log" 2>&1 || exit 1; }
 mkdir -p "$out"
-run ta TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum
-run ta2 TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum
-run tcp1 TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum
-run tcp2 TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_LATENCY_sum TCP_TOTAL_READ_sum TCP_GATE_EN1_sum
+run fetch FETCH_SIZE
+run write WRITE_SIZE
+run tcc1 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum
+run tcc2 TCC_EA0_RDREQ_32B_sum TCC_EA0_RD_UNCACHED_32B_sum TCC_TAG_STALL_sum TCC_EA0_RDREQ_DRAM_sum
 run grbm GRBM_GUI_ACTIVE GRBM_COUNT

@@ -92,6 +92,11 @@ class rt_bvh_node(C.Structure):
                 ("flags", C.c_uint32), ("_pad", C.c_uint32)]
 
 
+class rt_wide_node(C.Structure):
+    _fields_ = [("child", C.c_uint32 * 4), ("box32", (C.c_double * 6) * 4), ("box8", (C.c_double * 6) * 4),
+                ("has_box8", C.c_int32), ("_pad", C.c_int32)]
+
+
 class rt_scene_info(C.Structure):
     _fields_ = [("n_nodes", C.c_uint64), ("n_lists", C.c_uint64), ("n_xforms", C.c_uint64), ("n_media", C.c_uint64),
                 ("n_lights", C.c_uint64), ("world_ref", C.c_uint32), ("max_stack", C.c_uint32),
@@ -136,6 +141,8 @@ PROTOTYPES = {
     "rt_scene_destroy": (C.c_int, [C.c_void_p]),
     "rt_scene_get_info": (C.c_int, [C.c_void_p, C.POINTER(rt_scene_info)]),
     "rt_scene_get_nodes": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(rt_bvh_node)]),
+    "rt_scene_wide_node_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "rt_scene_get_wide_nodes": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(rt_wide_node)]),
     "rt_scene_object_bounds": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_double)]),
     "rt_closest_hit": (C.c_int, [C.c_void_p, C.POINTER(rt_ray_batch), C.c_uint64, C.POINTER(rt_hit_batch), C.c_uint64, C.c_uint32]),
     "rt_closest_hit_device": (C.c_int, [C.c_void_p, C.POINTER(rt_ray_batch), C.c_uint64, C.POINTER(rt_hit_batch), C.c_uint64, C.c_uint32, C.c_void_p]),

@@ -2,9 +2,13 @@
 // (the reference's Mesh, mesh.rs:95-183, or a BvhNode over spheres/quads/triangles).
 //
 // Same results as the general traversal in ordered mode; built for throughput:
-//   - 4-wide nodes: two levels of the binary tree in one 128-byte record (one cache line), boxes
-//     rounded outward to f32 and tested with a conservative f32 slab test; children are entered
-//     nearest first.  Half as many dependent fetches per ray as the binary tree;
+//   - 4-wide nodes: two levels of the binary tree in one record, boxes tested with a conservative f32
+//     slab test; children are entered nearest first.  Half as many dependent fetches per ray as the
+//     binary tree.  Two record formats: 128 bytes with f32 boxes (QNode), or 64 bytes with 8-bit
+//     boxes on a per-node grid (CQNode, QUANT = true).  On MI355X a divergent per-lane load costs the
+//     vector L1 about two cycles per (lane, 16-byte request) whether or not a lane's requests fall
+//     into one line (profiles/gather_probe.hip), and with f32 nodes that request rate is what bounds
+//     the kernel; the 64-byte record needs four requests per visit instead of seven;
 //   - stack entries carry the entry distance of the deferred child, so a subtree that the closest
 //     hit has overtaken since it was pushed is dropped at pop time without fetching its node;
 //     the newest 8 entries per lane sit in LDS, deeper ones spill to HBM (rare);
@@ -22,6 +26,7 @@ namespace rt {
 
 constexpr int FAST_BLOCK = 256;
 constexpr int REFILL_THRESHOLD = 40; // refill when fewer lanes than this are still traversing
+constexpr int POP_TRIPS = 2;         // stack entries a lane may take (and discard) per iteration
 constexpr int LEAF_VOTE = 24;        // lanes that must stand on a primitive before the wave runs the intersector
 
 // Conservative f32 slab test of the fast kernel.  For one axis the entry / exit parameters of the
@@ -107,13 +112,16 @@ struct LaneStack {
         RT_STACK_SLOT((st).sp) = e_;                                                          \
         ++(st).sp;                                                                            \
     } while (0)
-// The LDS slot is read unconditionally and overridden by the spilled entry when there is one: a
-// conditional choice between the two loads makes hipcc (ROCm 7.2) merge them into one load through
-// a generic pointer, which its gfx950 backend then fails to select.
+// The LDS slot is read unconditionally and overridden by the spilled entry when there is one.  The
+// empty asm pins the LDS value in registers before the branch: without it hipcc (ROCm 7.2) merges the
+// two loads into ONE flat load through a selected generic pointer, and a flat load of an LDS address
+// takes the long way through the vector memory path (measured: 39 % of the kernel's wave time sat in
+// the pop loop waiting for it).
 #define RT_STACK_POP(st, out)                                                                 \
     do {                                                                                      \
         --(st).sp;                                                                            \
         (out) = RT_STACK_SLOT((st).sp);                                                       \
+        asm volatile("" : "+v"((out).x), "+v"((out).y));                                      \
         if ((st).sp < (st).base) { (st).base = (st).sp; (out) = (st).spill[(size_t)(st).sp * (st).spill_stride]; } \
     } while (0)
 
@@ -124,29 +132,23 @@ RT_DEV void order2(float& ka, uint32_t& ra, float& kb, uint32_t& rb) { // ascend
     ka = k0; kb = k1; ra = r0; rb = r1;
 }
 
-// Node fetch.  A lane that reads its own 128-byte node issues eight 16-byte requests, and the
-// vector L1 of a CU handles divergent requests at a fixed rate per (lane, request) no matter that
-// they fall into one line: measured on MI355X, per-lane pointer chasing delivers 47 G rows/s with
-// seven requests per row but 145 G rows/s when the eight lanes of a group read the eight 16-byte
-// pieces of ONE row in a single instruction (one line request) and the rows are handed to their
-// owners through LDS (profiles/gather_probe.hip).  COOP selects that cooperative fetch: eight load
-// instructions bring the 64 nodes of the wave into a per-wave 8 KB staging area, each lane then
-// reads its own node back.  Chunk c of row r is kept at position c ^ (r & 7), which makes both the
-// row-wise writes and the lane-wise reads bank-conflict free without padding.
-constexpr int STAGE_CHUNKS = 8; // 16-byte chunks per staged row (one QNode)
-#define RT_STAGE(row, chunk) s_stage[((wave_in_block * 64 + (row)) * STAGE_CHUNKS) + ((chunk) ^ ((row) & 7))]
+// Node fetch: each lane reads its own node.  A cooperative variant (the eight lanes of a group read
+// the eight 16-byte pieces of one node in a single instruction, nodes handed to their owners through
+// LDS) reaches three times the gather rate in isolation (profiles/gather_probe.hip) but was slower
+// here: it issues the loads of all 64 lanes whether or not they stand on a node, and its 8 KB of
+// staging per wave costs occupancy.
+
+RT_DEV float ubyte_f32(uint32_t w, int byte) { return (float)((w >> (8 * byte)) & 0xFFu); } // v_cvt_f32_ubyteN
 
 // PRIM: RT_REF_TRI / RT_REF_SPHERE / RT_REF_QUAD when every leaf has that kind, 0 for mixed leaves.
-template <int PRIM, bool COUNT, bool COOP>
+template <int PRIM, bool COUNT, bool QUANT>
 __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, uint32_t root, rt_ray_batch rays,
                                                                        unsigned long long n_in, RayQueue rq, uint32_t opt, double tmin_default,
                                                                        float scene_extent, double* out_t, uint32_t* out_prim,
                                                                        unsigned long long* work_counter,
                                                                        unsigned long long* stat_counters, uint2* spill, int refill_threshold,
-                                                                       int leaf_vote, int chunk) {
+                                                                       int leaf_vote, int chunk, int pop_trips) {
     __shared__ uint2 s_fast_stack[LDS_STACK * FAST_BLOCK];
-    __shared__ float4 s_stage[COOP ? FAST_BLOCK * STAGE_CHUNKS : 1];
-    const uint32_t wave_in_block = threadIdx.x >> 6;
     LaneStack st;
     st.spill_stride = (size_t)gridDim.x * FAST_BLOCK;
     st.spill = spill + (size_t)blockIdx.x * FAST_BLOCK + threadIdx.x;
@@ -154,10 +156,11 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, 
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lane_below = (1ull << lane) - 1ull;
     const unsigned long long n = rq.count ? *rq.count : n_in;
-    const char* const qbase = reinterpret_cast<const char*>(S.qnodes);
+    const char* const qbase = QUANT ? reinterpret_cast<const char*>(S.cqnodes) : reinterpret_cast<const char*>(S.qnodes);
 
     bool active = false;
-    bool more = true; // wave-uniform: the counter may still hold rays
+    bool pop = false;  // the lane has to take its next node or primitive from the stack
+    bool more = true;  // wave-uniform: the counter may still hold rays
     unsigned long long wave_next = 0, wave_end = 0; // wave-uniform: the part of the batch this wave still owns
     RayD r;
     Ray32 q;
@@ -167,6 +170,9 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, 
     unsigned long long ray_slot = 0;
     uint32_t nn = 0, np = 0;
     // wave-level occupancy diagnostics (COUNT builds only): how many lanes take part in each phase
+    unsigned long long c_refill = 0, c_node = 0, c_leaf = 0, c_pop = 0, c_mark = 0; // wave cycles per phase (s_memtime)
+#define RT_TICK(acc) do { if (COUNT) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); (acc) += now_ - c_mark; c_mark = now_; } } while (0)
+    if (COUNT) c_mark = __builtin_amdgcn_s_memtime();
     uint32_t d_iters = 0, d_node_lanes = 0, d_tri_phases = 0, d_tri_lanes = 0, d_pop_iters = 0, d_pop_lanes = 0, d_rounds = 0, d_run_lanes = 0;
 
     for (;;) {
@@ -207,67 +213,79 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, 
                         cur = root;
                         RT_STACK_RESET(st);
                         active = true;
+                        pop = false;
                     }
                 }
                 const unsigned long long left = wave_end - wave_next, want = (unsigned long long)__popcll(idle);
                 wave_next += want < left ? want : left;
             }
         }
+        RT_TICK(c_refill);
         if (!__any(active)) break;
 
-        // Wave-uniform loop: every lane keeps executing (a finished lane still serves as a helper of
-        // the cooperative fetch) until the wave is empty or enough lanes are idle to refill.
+        // Wave-uniform loop: runs until the wave is empty or enough lanes are idle to refill.
         for (;;) {
             // One iteration = (1) lanes standing on a node take a node step, (2) lanes standing on a
             // primitive test it once enough of the wave stands on one (LEAF_VOTE lanes, or every
             // lane still running), (3) lanes whose node missed or whose primitive was tested pop.
             // Holding primitive tests back until a quorum is reached keeps the f64 intersector from
             // running with a handful of lanes while the rest of the wave waits.
-            const bool at_node = active && (cur >> 28) == RT_REF_NODE;
+            const bool at_node = active && !pop && (cur >> 28) == RT_REF_NODE;
             if (COUNT) { ++d_iters; d_run_lanes += __popcll(__ballot(active)); d_node_lanes += __popcll(__ballot(at_node)); }
-            bool pop = false;
-            if (COOP) {
-                // lanes without a node ask for the root's row, which stays in cache
-                const uint32_t my_row = at_node ? (cur & 0x0FFFFFFFu) : (root & 0x0FFFFFFFu);
-                const uint32_t sub = lane & 7u, grp = lane & ~7u;
-                float4 piece[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const uint32_t rrow = (uint32_t)__shfl((int)my_row, (int)(grp + k));
-                    piece[k] = reinterpret_cast<const float4*>(qbase + (size_t)rrow * sizeof(QNode))[sub];
-                }
-#pragma unroll
-                for (int k = 0; k < 8; ++k) RT_STAGE(grp + k, sub) = piece[k];
-                __builtin_amdgcn_wave_barrier();
-            }
             if (at_node) {
-                float4 lox, loy, loz, hix, hiy, hiz, chf;
-                if (COOP) {
-                    lox = RT_STAGE(lane, 0); loy = RT_STAGE(lane, 1); loz = RT_STAGE(lane, 2);
-                    hix = RT_STAGE(lane, 3); hiy = RT_STAGE(lane, 4); hiz = RT_STAGE(lane, 5);
-                    chf = RT_STAGE(lane, 6);
+                uint4 ch;
+                float nx[4], fx[4], ny[4], fy[4], nz[4], fz[4]; // entry / exit plane per axis and child
+                float ax, ay, az, bnx, bfx, bny, bfy, bnz, bfz; // t(plane) = plane * a + b
+                if (QUANT) {
+                    const uint4* row = reinterpret_cast<const uint4*>(qbase + (size_t)(cur & 0x0FFFFFFFu) * sizeof(CQNode));
+                    const uint4 h0 = row[0]; // origin x y z | exp x, exp y, exp z
+                    ch = row[1];
+                    const uint4 qa = row[2]; // qlo x | qlo y | qlo z | qhi x   (one byte per child)
+                    const uint4 qb = row[3]; // qhi y | qhi z
+                    // t(plane) = (origin + g * step - o) / d = g * (step * inv) + (origin * inv + c): with
+                    // |origin + g * step| <= M the rounding errors of this form stay below the margin E
+                    // (at most 7 * 2^-24 * |inv| * (M + |o|)), see Ray32
+                    ax = __uint_as_float((h0.w & 0xFFu) << 23) * q.inv[0];
+                    ay = __uint_as_float(((h0.w >> 8) & 0xFFu) << 23) * q.inv[1];
+                    az = __uint_as_float(((h0.w >> 16) & 0xFFu) << 23) * q.inv[2];
+                    const float ox = __uint_as_float(h0.x), oy = __uint_as_float(h0.y), oz = __uint_as_float(h0.z);
+                    bnx = __builtin_fmaf(ox, q.inv[0], q.cn[0]); bfx = __builtin_fmaf(ox, q.inv[0], q.cf[0]);
+                    bny = __builtin_fmaf(oy, q.inv[1], q.cn[1]); bfy = __builtin_fmaf(oy, q.inv[1], q.cf[1]);
+                    bnz = __builtin_fmaf(oz, q.inv[2], q.cn[2]); bfz = __builtin_fmaf(oz, q.inv[2], q.cf[2]);
+                    const uint32_t nxw = q.neg[0] ? qa.w : qa.x, fxw = q.neg[0] ? qa.x : qa.w;
+                    const uint32_t nyw = q.neg[1] ? qb.x : qa.y, fyw = q.neg[1] ? qa.y : qb.x;
+                    const uint32_t nzw = q.neg[2] ? qb.y : qa.z, fzw = q.neg[2] ? qa.z : qb.y;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        nx[j] = ubyte_f32(nxw, j); fx[j] = ubyte_f32(fxw, j);
+                        ny[j] = ubyte_f32(nyw, j); fy[j] = ubyte_f32(fyw, j);
+                        nz[j] = ubyte_f32(nzw, j); fz[j] = ubyte_f32(fzw, j);
+                    }
                 } else {
                     const float4* row = reinterpret_cast<const float4*>(qbase + (size_t)(cur & 0x0FFFFFFFu) * sizeof(QNode));
-                    lox = row[0]; loy = row[1]; loz = row[2];
-                    hix = row[3]; hiy = row[4]; hiz = row[5];
-                    chf = row[6];
+                    const float4 lox = row[0], loy = row[1], loz = row[2];
+                    const float4 hix = row[3], hiy = row[4], hiz = row[5];
+                    const float4 chf = row[6];
+                    ch = make_uint4(__float_as_uint(chf.x), __float_as_uint(chf.y), __float_as_uint(chf.z), __float_as_uint(chf.w));
+                    const float lx[4] = {lox.x, lox.y, lox.z, lox.w}, hx[4] = {hix.x, hix.y, hix.z, hix.w};
+                    const float ly[4] = {loy.x, loy.y, loy.z, loy.w}, hy[4] = {hiy.x, hiy.y, hiy.z, hiy.w};
+                    const float lz[4] = {loz.x, loz.y, loz.z, loz.w}, hz[4] = {hiz.x, hiz.y, hiz.z, hiz.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        nx[j] = q.neg[0] ? hx[j] : lx[j]; fx[j] = q.neg[0] ? lx[j] : hx[j];
+                        ny[j] = q.neg[1] ? hy[j] : ly[j]; fy[j] = q.neg[1] ? ly[j] : hy[j];
+                        nz[j] = q.neg[2] ? hz[j] : lz[j]; fz[j] = q.neg[2] ? lz[j] : hz[j];
+                    }
+                    ax = q.inv[0]; ay = q.inv[1]; az = q.inv[2];
+                    bnx = q.cn[0]; bfx = q.cf[0]; bny = q.cn[1]; bfy = q.cf[1]; bnz = q.cn[2]; bfz = q.cf[2];
                 }
-                const uint4 ch = make_uint4(__float_as_uint(chf.x), __float_as_uint(chf.y), __float_as_uint(chf.z), __float_as_uint(chf.w));
-                const float nx[4] = {q.neg[0] ? hix.x : lox.x, q.neg[0] ? hix.y : lox.y, q.neg[0] ? hix.z : lox.z, q.neg[0] ? hix.w : lox.w};
-                const float fx[4] = {q.neg[0] ? lox.x : hix.x, q.neg[0] ? lox.y : hix.y, q.neg[0] ? lox.z : hix.z, q.neg[0] ? lox.w : hix.w};
-                const float ny[4] = {q.neg[1] ? hiy.x : loy.x, q.neg[1] ? hiy.y : loy.y, q.neg[1] ? hiy.z : loy.z, q.neg[1] ? hiy.w : loy.w};
-                const float fy[4] = {q.neg[1] ? loy.x : hiy.x, q.neg[1] ? loy.y : hiy.y, q.neg[1] ? loy.z : hiy.z, q.neg[1] ? loy.w : hiy.w};
-                const float nz[4] = {q.neg[2] ? hiz.x : loz.x, q.neg[2] ? hiz.y : loz.y, q.neg[2] ? hiz.z : loz.z, q.neg[2] ? hiz.w : loz.w};
-                const float fz[4] = {q.neg[2] ? loz.x : hiz.x, q.neg[2] ? loz.y : hiz.y, q.neg[2] ? loz.z : hiz.z, q.neg[2] ? loz.w : hiz.w};
                 uint32_t rf[4] = {ch.x, ch.y, ch.z, ch.w};
                 float key[4];
                 int nh = 0;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float tn = fmaxf(fmaxf(__builtin_fmaf(nx[j], q.inv[0], q.cn[0]), __builtin_fmaf(ny[j], q.inv[1], q.cn[1])),
-                                           fmaxf(__builtin_fmaf(nz[j], q.inv[2], q.cn[2]), tmin32));
-                    const float tf = fminf(fminf(__builtin_fmaf(fx[j], q.inv[0], q.cf[0]), __builtin_fmaf(fy[j], q.inv[1], q.cf[1])),
-                                           fminf(__builtin_fmaf(fz[j], q.inv[2], q.cf[2]), best32));
+                    const float tn = fmaxf(fmaxf(__builtin_fmaf(nx[j], ax, bnx), __builtin_fmaf(ny[j], ay, bny)), fmaxf(__builtin_fmaf(nz[j], az, bnz), tmin32));
+                    const float tf = fminf(fminf(__builtin_fmaf(fx[j], ax, bfx), __builtin_fmaf(fy[j], ay, bfy)), fminf(__builtin_fmaf(fz[j], az, bfz), best32));
                     const bool hit = (tn <= tf) && (rf[j] != RT_REF_NONE);
                     key[j] = hit ? tn : __builtin_inff();
                     nh += hit ? 1 : 0;
@@ -288,7 +306,7 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, 
                     pop = true;
                 }
             }
-            if (COOP) __builtin_amdgcn_wave_barrier(); // staged rows are consumed before the next fetch overwrites them
+            RT_TICK(c_node);
             {
                 const bool at_leaf = active && !pop && (cur >> 28) != RT_REF_NODE;
                 const unsigned long long leaf_mask = __ballot(at_leaf);
@@ -316,13 +334,18 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, 
                     pop = true;
                 }
             }
+            RT_TICK(c_leaf);
             if (COUNT) { const unsigned long long pm = __ballot(pop); if (pm) { ++d_pop_iters; d_pop_lanes += __popcll(pm); } }
             if (pop) {
-                for (;;) {
+                // At most pop_trips entries are taken per iteration.  After a hit most of a lane's stack is
+                // stale (farther than the hit); discarding it all at once would keep the whole wave in this
+                // loop with one or two lanes working, so the rest is left for the following iterations.
+                for (int trip = 0; trip < pop_trips; ++trip) {
                     if (st.sp == 0) {
                         out_t[ray_slot] = best_ref == RT_REF_NONE ? D_INF : best_t;
                         out_prim[ray_slot] = best_ref;
                         active = false;
+                        pop = false;
                         break;
                     }
                     uint2 e;
@@ -330,9 +353,10 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, 
                     // e.y is a lower bound of the distance at which the deferred subtree is entered;
                     // closed-interval primitives may still tie at exactly best_t, so only strictly
                     // farther subtrees are dropped
-                    if (!(__uint_as_float(e.y) > best32)) { cur = e.x; break; }
+                    if (!(__uint_as_float(e.y) > best32)) { cur = e.x; pop = false; break; }
                 }
             }
+            RT_TICK(c_pop);
             const int running = __popcll(__ballot(active));
             if (running == 0 || (more && running < refill_threshold)) break;
         }
@@ -349,6 +373,10 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, 
             atomicAdd(&stat_counters[9], (unsigned long long)d_pop_lanes);
             atomicAdd(&stat_counters[10], (unsigned long long)d_rounds);
             atomicAdd(&stat_counters[11], (unsigned long long)d_run_lanes);
+            atomicAdd(&stat_counters[12], c_refill);
+            atomicAdd(&stat_counters[13], c_node);
+            atomicAdd(&stat_counters[14], c_leaf);
+            atomicAdd(&stat_counters[15], c_pop);
         }
     }
 }

@@ -42,10 +42,14 @@ struct alignas(16) DQuad {     // 144 B (quad.rs:15-25 without the bbox)
     int32_t _pad;
 };
 
-struct alignas(8) DTri {       // 72 B: the three vertices the intersector reads (triangle.rs:113-115)
+// The three vertices the intersector reads (triangle.rs:113-115): 72 bytes in a 128-byte slot, so a
+// triangle test fetches exactly one line from HBM (packed at 72 bytes every second record straddles two,
+// and the primitive-BVH kernel is bound by the number of lines it pulls through the fabric).
+struct alignas(128) DTri {
     double v0[3];
     double v1[3];
     double v2[3];
+    double _pad[7];
 };
 
 struct alignas(16) DTriAux {   // 32 B: read once per accepted hit
@@ -76,28 +80,17 @@ struct alignas(128) QNode {
     uint32_t _pad[4];
 };
 
-// 8-wide compressed node of the triangle-mesh kernel, 80 bytes = five 16-byte requests per visit.
-// Child boxes are 8-bit grid coordinates on the node's own grid: plane = origin[a] + q * 2^(exp[a]-127),
-// minima rounded down and maxima rounded up, so every child box contains the f32 box it came from.
-// Inner children are consecutive nodes starting at child_base, leaf children consecutive records of
-// the reordered triangle array starting at prim_base.
-struct alignas(16) CNode {
-    float origin[3];           // lower corner of the node's box
+// The same 4-wide node in 64 bytes, read with four 16-byte requests instead of seven.  Child boxes
+// are 8-bit grid coordinates on the node's own grid: plane = origin[a] + q * 2^(exp[a] - 127), minima
+// rounded down and maxima rounded up, so every stored box contains the f32 box it came from.
+struct alignas(64) CQNode {
+    float origin[3];           // lower corner of the union of the child boxes
     uint8_t exp[3];            // biased exponent of the grid step per axis
-    uint8_t valid;             // bit i: child slot i is used
-    uint32_t child_base;
-    uint32_t prim_base;
-    uint8_t meta[8];           // per slot: 0x80 | k = leaf ctris[prim_base + k], k = inner cnodes[child_base + k]
-    uint8_t qlo[3][8];         // [axis][slot]
-    uint8_t qhi[3][8];
-};
-
-struct alignas(16) CTri {      // 80 B: triangle of the compressed BVH, stored in leaf order
-    double v0[3];
-    double v1[3];
-    double v2[3];
-    uint32_t ref;              // reference of the triangle in the description order (RT_REF_TRI | index)
-    uint32_t _pad;
+    uint8_t _pad0;
+    uint32_t child[4];         // as QNode::child
+    uint8_t qlo[3][4];         // [axis][child]
+    uint8_t qhi[3][4];
+    uint32_t _pad[2];
 };
 
 struct DList { uint32_t first, count; };
@@ -139,8 +132,7 @@ struct DScene {
     const DNode* nodes;
     const WNode* wnodes;
     const QNode* qnodes;
-    const CNode* cnodes;
-    const CTri* ctris;
+    const CQNode* cqnodes;
     const DSphere* spheres;
     const DQuad* quads;
     const DTri* tris;

@@ -495,12 +495,15 @@ struct Flattener {
         return RT_OK;
     }
 
-    // Collapses two levels of the binary tree under wide node `idx` into one 4-wide node.
-    // Children keep the reference's left-to-right order; which of them is entered first is decided
-    // per ray at run time.  Returns the q-index.  `depth_out` = stack entries a traversal below needs.
-    uint32_t build_qnode(uint32_t idx, int32_t& need_out) {
-        const uint32_t me = (uint32_t)f.qnodes.size();
-        f.qnodes.emplace_back();
+    // Collapses two levels of the binary tree under wide node `idx` into the 4-wide node `me` (already
+    // allocated).  Children keep the reference's left-to-right order; which of them is entered first is
+    // decided per ray at run time.  The inner children of a node get consecutive indices starting at an
+    // even one, so that siblings share 128-byte lines (two 64-byte nodes per line): a ray that enters
+    // several children of a node finds the later ones in a line it has already pulled in.
+    // Returns the stack entries a traversal below this node can need.
+    std::vector<uint8_t> qdepth; // depth of every 4-wide node below the root of its tree
+    int32_t fill_qnode(uint32_t me, uint32_t idx, int depth) {
+        qdepth[me] = (uint8_t)std::min(depth, 255);
         uint32_t refs[4];
         float boxes[4][6];
         int n = 0;
@@ -517,13 +520,22 @@ struct Flattener {
             expand(w.left, w.lb);
             if (!(w.meta & 2u)) expand(w.right, w.rb);
         }
+        int n_inner = 0;
+        for (int j = 0; j < n; ++j) n_inner += RT_REF_KIND(refs[j]) == RT_REF_NODE ? 1 : 0;
+        uint32_t base = 0;
+        if (n_inner) {
+            if (f.qnodes.size() & 1u) add_empty_qnode(); // pad: sibling groups start on a line boundary
+            base = (uint32_t)f.qnodes.size();
+            for (int k = 0; k < n_inner; ++k) add_empty_qnode();
+        }
         int32_t deepest = 0;
         uint32_t out_refs[4] = {RT_REF_NONE, RT_REF_NONE, RT_REF_NONE, RT_REF_NONE};
+        int k = 0;
         for (int j = 0; j < n; ++j) {
             if (RT_REF_KIND(refs[j]) == RT_REF_NODE) {
-                int32_t nd = 0;
-                out_refs[j] = make_ref(RT_REF_NODE, build_qnode(RT_REF_INDEX(refs[j]), nd));
-                deepest = std::max(deepest, nd);
+                const uint32_t child = base + (uint32_t)k++;
+                out_refs[j] = make_ref(RT_REF_NODE, child);
+                deepest = std::max(deepest, fill_qnode(child, RT_REF_INDEX(refs[j]), depth + 1));
             } else out_refs[j] = refs[j];
         }
         QNode& q = f.qnodes[me];
@@ -536,94 +548,72 @@ struct Flattener {
                 q.hi[a][j] = j < n ? boxes[j][2 * a + 1] : -std::numeric_limits<float>::infinity();
             }
         }
-        need_out = (n - 1) + deepest; // up to n-1 siblings stay on the stack while one child is traversed
-        return me;
+        return (n - 1) + deepest; // up to n-1 siblings stay on the stack while one child is traversed
+    }
+    void add_empty_qnode() { // all four slots empty: never entered, keeps the index arithmetic simple
+        QNode q{};
+        for (int j = 0; j < 4; ++j) {
+            q.child[j] = RT_REF_NONE;
+            for (int a = 0; a < 3; ++a) { q.lo[a][j] = std::numeric_limits<float>::infinity(); q.hi[a][j] = -std::numeric_limits<float>::infinity(); }
+        }
+        f.qnodes.push_back(q);
+        qdepth.push_back(255);
     }
 
-    // 8-wide compressed collapse (triangle leaves only).  Starting from the two children of binary node
-    // `idx`, the inner child with the largest surface area is replaced by its own children until eight
-    // slots are used or only leaves remain; a one-object span (bvh.rs:41-44) contributes its object once.
-    // Child boxes are snapped outward onto the node's 8-bit grid.  Fills cnodes[me]; returns the stack
-    // entries a traversal below this node can need.
-    struct CItem { uint32_t ref; float box[6]; };
-    static double box_area(const float* b) {
-        const double dx = (double)b[1] - b[0], dy = (double)b[3] - b[2], dz = (double)b[5] - b[4];
-        return dx * dy + dy * dz + dz * dx;
-    }
-    int children_of(uint32_t node_idx, CItem* out) const {
-        const WNode& c = f.wnodes[node_idx];
-        out[0].ref = c.left;
-        std::copy(c.lb, c.lb + 6, out[0].box);
-        if (c.meta & 2u) return 1;
-        out[1].ref = c.right;
-        std::copy(c.rb, c.rb + 6, out[1].box);
-        return 2;
-    }
-    int32_t fill_cnode(uint32_t me, uint32_t idx) {
-        CItem items[8];
-        int n = children_of(idx, items);
-        while (n < 8) {
-            int pick = -1;
-            double best = -1.0;
-            for (int j = 0; j < n; ++j)
-                if (RT_REF_KIND(items[j].ref) == RT_REF_NODE) {
-                    const double a = box_area(items[j].box);
-                    if (pick < 0 || a > best) { best = a; pick = j; }
+    // 8-bit copy of every 4-wide node (same indices).  Returns the mean, over the child boxes of the top
+    // four levels (the nodes nearly every ray passes), of (surface area quantised / surface area f32), each
+    // ratio capped at 16: close to 1 when siblings are of similar size, large when one huge primitive forces
+    // a coarse grid onto its small neighbours all the way up the tree (then the f32 nodes are the better choice).
+    double quantise_qnodes() {
+        f.cqnodes.resize(f.qnodes.size());
+        double ratio_sum = 0.0;
+        uint64_t ratio_n = 0;
+        auto area = [](const double* lo, const double* hi) {
+            const double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+            return dx * dy + dy * dz + dz * dx;
+        };
+        for (size_t i = 0; i < f.qnodes.size(); ++i) {
+            const QNode& s = f.qnodes[i];
+            CQNode q{};
+            int n = 0;
+            for (int j = 0; j < 4; ++j) { q.child[j] = s.child[j]; if (s.child[j] != RT_REF_NONE) n = j + 1; }
+            double step[3];
+            for (int a = 0; a < 3; ++a) {
+                float lo = s.lo[a][0], hi = s.hi[a][0];
+                for (int j = 1; j < n; ++j) { lo = std::min(lo, s.lo[a][j]); hi = std::max(hi, s.hi[a][j]); }
+                q.origin[a] = lo;
+                const double extent = (double)hi - (double)lo;
+                int e = 1; // biased exponent of the grid step (a normal float): 255 steps must span the extent
+                if (extent > 0.0) {
+                    int ex;
+                    std::frexp(extent / 255.0, &ex);
+                    e = std::min(254, std::max(1, ex + 127));
+                    while (e < 254 && std::ldexp(255.0, e - 127) < extent) ++e;
                 }
-            if (pick < 0) break;
-            CItem sub[2];
-            const int m = children_of(RT_REF_INDEX(items[pick].ref), sub);
-            items[pick] = sub[0];
-            if (m == 2) items[n++] = sub[1];
-        }
-        CNode c{};
-        for (int a = 0; a < 3; ++a) {
-            float lo = items[0].box[2 * a], hi = items[0].box[2 * a + 1];
-            for (int j = 1; j < n; ++j) { lo = std::min(lo, items[j].box[2 * a]); hi = std::max(hi, items[j].box[2 * a + 1]); }
-            c.origin[a] = lo;
-            const double extent = (double)hi - (double)lo;
-            int e = 1; // biased exponent of the grid step, a normal float: 1..254
-            if (extent > 0.0) {
-                int ex;
-                std::frexp(extent / 255.0, &ex); // extent/255 = m * 2^ex, m in [0.5, 1): 2^ex >= extent/255
-                e = std::min(254, std::max(1, ex + 127));
-                while (e < 254 && std::ldexp(255.0, e - 127) < extent) ++e;
+                q.exp[a] = (uint8_t)e;
+                step[a] = std::ldexp(1.0, e - 127);
+                for (int j = 0; j < 4; ++j) {
+                    if (j >= n) { q.qlo[a][j] = 255; q.qhi[a][j] = 0; continue; } // never tested: the slot's child is RT_REF_NONE
+                    const double l = (double)s.lo[a][j] - (double)lo, h = (double)s.hi[a][j] - (double)lo;
+                    double ql = std::floor(l / step[a]), qh = std::ceil(h / step[a]);
+                    while (ql > 0.0 && ql * step[a] > l) ql -= 1.0;
+                    while (qh < 255.0 && qh * step[a] < h) qh += 1.0;
+                    q.qlo[a][j] = (uint8_t)std::min(255.0, std::max(0.0, ql));
+                    q.qhi[a][j] = (uint8_t)std::min(255.0, std::max(0.0, qh));
+                }
             }
-            c.exp[a] = (uint8_t)e;
-            const double step = std::ldexp(1.0, e - 127);
-            for (int j = 0; j < 8; ++j) {
-                if (j >= n) { c.qlo[a][j] = 255; c.qhi[a][j] = 0; continue; }
-                const double l = (double)items[j].box[2 * a] - (double)lo, h = (double)items[j].box[2 * a + 1] - (double)lo;
-                double ql = std::floor(l / step), qh = std::ceil(h / step);
-                while (ql > 0.0 && ql * step > l) ql -= 1.0;
-                while (qh < 255.0 && qh * step < h) qh += 1.0;
-                c.qlo[a][j] = (uint8_t)std::min(255.0, std::max(0.0, ql));
-                c.qhi[a][j] = (uint8_t)std::min(255.0, std::max(0.0, qh));
+            for (int j = 0; j < n; ++j) {
+                double lo32[3], hi32[3], loq[3], hiq[3];
+                for (int a = 0; a < 3; ++a) {
+                    lo32[a] = s.lo[a][j]; hi32[a] = s.hi[a][j];
+                    loq[a] = q.origin[a] + q.qlo[a][j] * step[a]; hiq[a] = q.origin[a] + q.qhi[a][j] * step[a];
+                }
+                const double a32 = area(lo32, hi32), aq = area(loq, hiq);
+                if (qdepth[i] < 4 && a32 > 0.0 && std::isfinite(aq)) { ratio_sum += std::min(aq / a32, 16.0); ++ratio_n; }
             }
+            f.cqnodes[i] = q;
         }
-        uint32_t n_inner = 0, n_leaf = 0;
-        c.child_base = (uint32_t)f.cnodes.size();
-        c.prim_base = (uint32_t)f.ctris.size();
-        uint32_t inner_idx[8];
-        for (int j = 0; j < n; ++j) {
-            c.valid |= (uint8_t)(1u << j);
-            if (RT_REF_KIND(items[j].ref) == RT_REF_NODE) {
-                inner_idx[n_inner] = RT_REF_INDEX(items[j].ref);
-                c.meta[j] = (uint8_t)n_inner++;
-            } else {
-                const DTri& t = f.tris[RT_REF_INDEX(items[j].ref)];
-                CTri ct{};
-                std::copy(t.v0, t.v0 + 3, ct.v0); std::copy(t.v1, t.v1 + 3, ct.v1); std::copy(t.v2, t.v2 + 3, ct.v2);
-                ct.ref = items[j].ref;
-                f.ctris.push_back(ct);
-                c.meta[j] = (uint8_t)(0x80u | n_leaf++);
-            }
-        }
-        f.cnodes.resize(f.cnodes.size() + n_inner);
-        f.cnodes[me] = c;
-        int32_t deepest = 0;
-        for (uint32_t k = 0; k < n_inner; ++k) deepest = std::max(deepest, fill_cnode(c.child_base + k, inner_idx[k]));
-        return (n - 1) + deepest;
+        return ratio_n ? ratio_sum / (double)ratio_n : 1.0;
     }
 
     // Stack entries a traversal starting at `ref` can need.
@@ -708,17 +698,15 @@ struct Flattener {
             if (RT_REF_KIND(r) == RT_REF_LIST && f.lists[RT_REF_INDEX(r)].count == 1) r = f.list_items[f.lists[RT_REF_INDEX(r)].first];
             auto it = bvh_prim_only.find(r);
             if (RT_REF_KIND(r) == RT_REF_NODE && it != bvh_prim_only.end() && it->second) {
-                int32_t nd = 0;
-                f.qnodes.reserve(f.nodes.size() / 2 + 1);
-                f.fast_root = make_ref(RT_REF_NODE, build_qnode(RT_REF_INDEX(r), nd));
-                f.fast_stack = (uint32_t)nd + 1;
+                f.qnodes.reserve(f.nodes.size() / 2 + 16);
+                add_empty_qnode(); // the root
+                f.fast_root = make_ref(RT_REF_NODE, 0u);
+                f.fast_stack = (uint32_t)fill_qnode(0, RT_REF_INDEX(r), 0) + 1;
                 bool finite = true;
                 for (double v : f.world_bounds.b) finite = finite && std::isfinite(v);
-                if (finite && !f.tris.empty() && f.spheres.empty() && f.quads.empty()) {
-                    f.cnodes.reserve(f.nodes.size() / 3 + 8);
-                    f.ctris.reserve(f.tris.size());
-                    f.cnodes.emplace_back();
-                    f.fast8_stack = (uint32_t)fill_cnode(0, RT_REF_INDEX(r)) + 1;
+                if (finite) {
+                    f.quant_inflation = quantise_qnodes();
+                    if (f.quant_inflation > 1.25) f.cqnodes.clear();
                 }
             }
         }

@@ -16,8 +16,7 @@ struct FlatScene {
     std::vector<DNode> nodes;
     std::vector<WNode> wnodes;
     std::vector<QNode> qnodes;        // 4-wide collapse of the BVH at fast_root (empty otherwise)
-    std::vector<CNode> cnodes;        // 8-wide compressed collapse when every leaf of that BVH is a triangle
-    std::vector<CTri> ctris;          // its triangles in leaf order
+    std::vector<CQNode> cqnodes;      // the same nodes with 8-bit boxes (same indices); empty when the grid would be too coarse
     std::vector<DSphere> spheres;
     std::vector<DQuad> quads;
     std::vector<DTri> tris;
@@ -39,7 +38,7 @@ struct FlatScene {
     uint32_t max_stack = 0;
     uint32_t fast_root = RT_REF_NONE; // set when the world is one BVH whose leaves are all primitives
     uint32_t fast_stack = 0;          // stack entries the primitive-BVH kernel needs
-    uint32_t fast8_stack = 0;         // same for the compressed 8-wide tree (cnodes[0] is its root)
+    double quant_inflation = 0.0;     // mean surface-area ratio of the 8-bit child boxes to their f32 boxes
     bool has_medium = false;
     Box world_bounds;
 };

@@ -22,14 +22,13 @@
 #include "flatten.h"
 #include "shade.h"
 #include "bvh_kernel.h"
-#include "bvh8_kernel.h"
 
 using namespace rt;
 
 // ============================================================================ device code
 namespace {
 
-enum { C_WORK = 0, C_LIVE_IN = 1, C_LIVE_OUT = 2, C_NODES = 4, C_PRIMS = 5, C_RAYS = 6, C_WORDS = 16 };
+enum { C_WORK = 0, C_LIVE_IN = 1, C_LIVE_OUT = 2, C_NODES = 4, C_PRIMS = 5, C_RAYS = 6, C_WORDS = 24 };
 
 struct CamD { // Camera after initialize() (camera.rs:30-42)
     rt_camera_derived d;
@@ -298,11 +297,8 @@ struct rt_scene {
     int fast_grid_blocks = 0;
     size_t fast_lds = 0;
     uint2* fast_spill = nullptr; // HBM overflow of the per-lane stacks: [entry][thread]
-    bool fast8 = false;          // triangle mesh: traverse the 8-wide compressed tree (cnodes / ctris)
-    int fast8_grid_blocks = 0;
-    uint2* fast8_spill = nullptr;
     int fast_prim = 0;           // leaf kind of the primitive BVH when uniform, else 0
-    bool fast_coop = true;       // cooperative (LDS-staged) node fetch in the primitive-BVH kernel
+    bool fast_quant = false;     // the primitive-BVH kernel reads the 64-byte nodes with 8-bit boxes
     float fast_extent = 0.0f; // largest |coordinate| of the world box (error bound of the f32 slab test)
     // render workspace
     PathState ps{};
@@ -337,25 +333,20 @@ int upload(rt_scene* s, const std::vector<T>& v, const T** out) {
 }
 
 using FastKernel = void (*)(DScene, uint32_t, rt_ray_batch, unsigned long long, RayQueue, uint32_t, double, float, double*, uint32_t*,
-                            unsigned long long*, unsigned long long*, uint2*, int, int, int);
-template <bool COUNT, bool COOP> FastKernel fast_kernel_for(int prim) {
-    if (prim == (int)RT_REF_TRI) return bvh4_closest_hit_kernel<RT_REF_TRI, COUNT, COOP>;
-    if (prim == (int)RT_REF_SPHERE) return bvh4_closest_hit_kernel<RT_REF_SPHERE, COUNT, COOP>;
-    return bvh4_closest_hit_kernel<0, COUNT, COOP>;
+                            unsigned long long*, unsigned long long*, uint2*, int, int, int, int);
+template <bool COUNT, bool QUANT> FastKernel fast_kernel_for(int prim) {
+    if (prim == (int)RT_REF_TRI) return bvh4_closest_hit_kernel<RT_REF_TRI, COUNT, QUANT>;
+    if (prim == (int)RT_REF_SPHERE) return bvh4_closest_hit_kernel<RT_REF_SPHERE, COUNT, QUANT>;
+    return bvh4_closest_hit_kernel<0, COUNT, QUANT>;
 }
-FastKernel fast_kernel(int prim, bool count, bool coop) {
-    if (coop) return count ? fast_kernel_for<true, true>(prim) : fast_kernel_for<false, true>(prim);
+FastKernel fast_kernel(int prim, bool count, bool quant) {
+    if (quant) return count ? fast_kernel_for<true, true>(prim) : fast_kernel_for<false, true>(prim);
     return count ? fast_kernel_for<true, false>(prim) : fast_kernel_for<false, false>(prim);
 }
 int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
     return e ? atoi(e) : dflt;
 }
-bool coop_setting() { // MI355RT_COOP=0 selects the per-lane node fetch (for A/B measurements)
-    const char* e = getenv("MI355RT_COOP");
-    return !(e && e[0] == '0');
-}
-
 int pick_grid(rt_scene* s) {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, s->device));
@@ -373,9 +364,9 @@ int pick_grid(rt_scene* s) {
         const bool tr = !s->flat.tris.empty(), sp = !s->flat.spheres.empty(), qd = !s->flat.quads.empty();
         s->fast_prim = (tr && !sp && !qd) ? (int)RT_REF_TRI : ((sp && !tr && !qd) ? (int)RT_REF_SPHERE : 0);
         int fast_per_cu = 0;
-        s->fast_coop = coop_setting();
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fast_per_cu, fast_kernel(s->fast_prim, false, s->fast_coop), FAST_BLOCK, 0));
-        if (getenv("MI355RT_DEBUG")) fprintf(stderr, "[mi355rt] primitive-BVH kernel: coop=%d blocks/CU=%d\n", (int)s->fast_coop, fast_per_cu);
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fast_per_cu, fast_kernel(s->fast_prim, false, s->fast_quant), FAST_BLOCK, 0));
+        if (getenv("MI355RT_DEBUG"))
+            fprintf(stderr, "[mi355rt] primitive-BVH kernel: 8-bit nodes=%d (inflation %.3f) blocks/CU=%d\n", (int)s->fast_quant, s->flat.quant_inflation, fast_per_cu);
         s->fast_grid_blocks = prop.multiProcessorCount * std::max(1, fast_per_cu);
         {
             size_t entries = (size_t)std::max<uint32_t>(s->flat.fast_stack, 1u);
@@ -386,21 +377,6 @@ int pick_grid(rt_scene* s) {
             s->device_bytes += bytes;
             s->fast_spill = static_cast<uint2*>(p);
         }
-        const char* e8 = getenv("MI355RT_BVH8"); // MI355RT_BVH8=0 keeps triangle meshes on the 4-wide kernel (A/B measurements)
-        s->fast8 = !s->flat.cnodes.empty() && !(e8 && e8[0] == '0');
-        if (s->fast8) {
-            int per_cu8 = 0;
-            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu8, bvh8_closest_hit_kernel<false>, FAST_BLOCK, 0));
-            if (getenv("MI355RT_DEBUG")) fprintf(stderr, "[mi355rt] compressed 8-wide kernel: blocks/CU=%d nodes=%zu\n", per_cu8, s->flat.cnodes.size());
-            s->fast8_grid_blocks = prop.multiProcessorCount * std::max(1, per_cu8);
-            size_t entries = (size_t)std::max<uint32_t>(s->flat.fast8_stack, 1u);
-            size_t bytes = entries * (size_t)s->fast8_grid_blocks * FAST_BLOCK * sizeof(uint2);
-            void* p = nullptr;
-            HIP_TRY(hipMalloc(&p, bytes));
-            s->allocs.push_back(p);
-            s->device_bytes += bytes;
-            s->fast8_spill = static_cast<uint2*>(p);
-        }
     }
     return RT_OK;
 }
@@ -408,7 +384,7 @@ int pick_grid(rt_scene* s) {
 void fill_host_dscene(rt_scene* s) {
     FlatScene& f = s->flat;
     DScene& d = s->dev;
-    d.nodes = f.nodes.data(); d.wnodes = f.wnodes.data(); d.qnodes = f.qnodes.data(); d.cnodes = f.cnodes.data(); d.ctris = f.ctris.data(); d.spheres = f.spheres.data(); d.quads = f.quads.data(); d.tris = f.tris.data();
+    d.nodes = f.nodes.data(); d.wnodes = f.wnodes.data(); d.qnodes = f.qnodes.data(); d.cqnodes = f.cqnodes.data(); d.spheres = f.spheres.data(); d.quads = f.quads.data(); d.tris = f.tris.data();
     d.tri_aux = f.tri_aux.data(); d.lists = f.lists.data(); d.list_items = f.list_items.data(); d.xforms = f.xforms.data();
     d.media = f.media.data(); d.materials = f.materials.data(); d.textures = f.textures.data(); d.images = f.images.data();
     d.image_bytes = f.image_bytes.data(); d.perlins = f.perlins.data(); d.lights = f.lights.data();
@@ -421,9 +397,13 @@ int upload_scene(rt_scene* s) {
     int rc;
     if ((rc = upload(s, f.nodes, &d.nodes))) return rc;
     if ((rc = upload(s, f.wnodes, &d.wnodes))) return rc;
-    if ((rc = upload(s, f.qnodes, &d.qnodes))) return rc;
-    if ((rc = upload(s, f.cnodes, &d.cnodes))) return rc;
-    if ((rc = upload(s, f.ctris, &d.ctris))) return rc;
+    // only the node format the primitive-BVH kernel will read goes to the device
+    // (MI355RT_QUANT=0 keeps the f32 nodes even when the 8-bit ones were accepted, for A/B measurements)
+    s->fast_quant = !f.cqnodes.empty() && env_int("MI355RT_QUANT", 1) != 0;
+    const std::vector<QNode> no_qnodes;
+    const std::vector<CQNode> no_cqnodes;
+    if ((rc = upload(s, s->fast_quant ? no_qnodes : f.qnodes, &d.qnodes))) return rc;
+    if ((rc = upload(s, s->fast_quant ? f.cqnodes : no_cqnodes, &d.cqnodes))) return rc;
     if ((rc = upload(s, f.spheres, &d.spheres))) return rc;
     if ((rc = upload(s, f.quads, &d.quads))) return rc;
     if ((rc = upload(s, f.tris, &d.tris))) return rc;
@@ -504,18 +484,11 @@ int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit
         const uint64_t waves_launched = (uint64_t)fblocks * (FAST_BLOCK / 64);
         const int chunk = env_int("MI355RT_CHUNK", (int)std::max<uint64_t>(16, std::min<uint64_t>(128, n / (waves_launched * 8))));
         auto flaunch = [&](auto kernel) {
-            hipLaunchKernelGGL(kernel, dim3(fblocks), dim3(FAST_BLOCK), 0, st, s->dev, s->flat.fast_root, *rays, (unsigned long long)n, rq, opt, 0.001,
+            hipLaunchKernelGGL(kernel, dim3(fblocks), dim3(FAST_BLOCK), (size_t)env_int("MI355RT_DYNLDS", 0), st, s->dev, s->flat.fast_root, *rays, (unsigned long long)n, rq, opt, 0.001,
                                s->fast_extent, hits->t, hits->prim, s->d_counters + C_WORK, s->d_counters + C_NODES, s->fast_spill,
-                               env_int("MI355RT_REFILL", REFILL_THRESHOLD), env_int("MI355RT_VOTE", LEAF_VOTE), chunk);
+                               env_int("MI355RT_REFILL", REFILL_THRESHOLD), env_int("MI355RT_VOTE", LEAF_VOTE), chunk, env_int("MI355RT_POP_TRIPS", POP_TRIPS));
         };
-        if (s->fast8) {
-            const int blocks8 = (int)std::min<uint64_t>((uint64_t)s->fast8_grid_blocks, (waves + (FAST_BLOCK / 64) - 1) / (FAST_BLOCK / 64));
-            hipLaunchKernelGGL(count ? bvh8_closest_hit_kernel<true> : bvh8_closest_hit_kernel<false>, dim3(blocks8), dim3(FAST_BLOCK), 0, st,
-                               s->dev, *rays, (unsigned long long)n, rq, opt, 0.001, s->fast_extent, hits->t, hits->prim, s->d_counters + C_WORK,
-                               s->d_counters + C_NODES, s->fast8_spill);
-        } else {
-            flaunch(fast_kernel(s->fast_prim, count, s->fast_coop));
-        }
+        flaunch(fast_kernel(s->fast_prim, count, s->fast_quant));
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(s->ev_hit1, st));
         if (hits->u || hits->v || hits->front_face || hits->mat || hits->nx || hits->ny || hits->nz || hits->px || hits->py || hits->pz)
@@ -675,6 +648,43 @@ int rt_scene_get_nodes(const rt_scene* s, uint64_t first, uint64_t count, rt_bvh
     return RT_OK;
 }
 
+int rt_scene_wide_node_count(const rt_scene* s, uint64_t* count) {
+    if (!s || !count) return set_err(RT_E_INVALID, "rt_scene_wide_node_count: null argument");
+    *count = s->flat.qnodes.size();
+    return RT_OK;
+}
+
+int rt_scene_get_wide_nodes(const rt_scene* s, uint64_t first, uint64_t count, rt_wide_node* out) {
+    if (!s || !out) return set_err(RT_E_INVALID, "rt_scene_get_wide_nodes: null argument");
+    if (first + count > s->flat.qnodes.size()) return set_err(RT_E_INVALID, "rt_scene_get_wide_nodes: range outside the node array");
+    const bool has8 = !s->flat.cqnodes.empty();
+    for (uint64_t i = 0; i < count; ++i) {
+        const QNode& q = s->flat.qnodes[first + i];
+        rt_wide_node& o = out[i];
+        o.has_box8 = has8 ? 1 : 0;
+        o._pad = 0;
+        for (int j = 0; j < 4; ++j) {
+            o.child[j] = q.child[j];
+            for (int a = 0; a < 3; ++a) {
+                o.box32[j][2 * a] = q.lo[a][j];
+                o.box32[j][2 * a + 1] = q.hi[a][j];
+                o.box8[j][2 * a] = o.box8[j][2 * a + 1] = 0.0;
+            }
+        }
+        if (has8) {
+            const CQNode& c = s->flat.cqnodes[first + i];
+            for (int a = 0; a < 3; ++a) {
+                const double step = std::ldexp(1.0, (int)c.exp[a] - 127);
+                for (int j = 0; j < 4; ++j) {
+                    o.box8[j][2 * a] = (double)c.origin[a] + (double)c.qlo[a][j] * step;
+                    o.box8[j][2 * a + 1] = (double)c.origin[a] + (double)c.qhi[a][j] * step;
+                }
+            }
+        }
+    }
+    return RT_OK;
+}
+
 int rt_scene_object_bounds(const rt_scene* s, int32_t object, double out[6]) {
     if (!s || !out) return set_err(RT_E_INVALID, "rt_scene_object_bounds: null argument");
     if (object < 0 || (size_t)object >= s->flat.object_bounds.size()) return set_err(RT_E_INVALID, "rt_scene_object_bounds: object id out of range");
@@ -827,6 +837,8 @@ int rt_get_counters(rt_scene* s, rt_counters* out) {
         if (getenv("MI355RT_DEBUG")) {
             std::fprintf(stderr, "[mi355rt] wave diag: iters %llu node_lanes %llu tri_phases %llu tri_lanes %llu pop_iters %llu pop_lanes %llu rounds %llu run_lanes %llu\n",
                          s->h_counters[8], s->h_counters[9], s->h_counters[10], s->h_counters[11], s->h_counters[12], s->h_counters[13], s->h_counters[14], s->h_counters[15]);
+            std::fprintf(stderr, "[mi355rt] wave cycles (s_memtime, summed over waves): refill %llu node %llu leaf %llu pop %llu\n", s->h_counters[16],
+                         s->h_counters[17], s->h_counters[18], s->h_counters[19]);
         }
     }
     *out = s->counters;

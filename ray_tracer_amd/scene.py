@@ -271,6 +271,16 @@ class Scene:
         dt = np.dtype([("bounds", "<f8", 6), ("left", "<u4"), ("right", "<u4"), ("flags", "<u4"), ("_pad", "<u4")])
         return np.frombuffer(buf, dtype=dt, count=n).copy()
 
+    def wide_nodes(self) -> np.ndarray:
+        """4-wide nodes of the primitive-BVH kernel (empty when the world is not one BVH over primitives)."""
+        cnt = C.c_uint64()
+        F.check(F.lib.rt_scene_wide_node_count(self._h, C.byref(cnt)))
+        n = cnt.value
+        buf = (F.rt_wide_node * max(1, n))()
+        F.check(F.lib.rt_scene_get_wide_nodes(self._h, 0, n, buf))
+        dt = np.dtype([("child", "<u4", 4), ("box32", "<f8", (4, 6)), ("box8", "<f8", (4, 6)), ("has_box8", "<i4"), ("_pad", "<i4")])
+        return np.frombuffer(buf, dtype=dt, count=n).copy()
+
     def object_bounds(self, obj: int) -> np.ndarray:
         out = (C.c_double * 6)()
         F.check(F.lib.rt_scene_object_bounds(self._h, obj, out))

@@ -198,3 +198,71 @@ def test_obj_reader_fan_triangulation(tmp_path):
     assert np.array_equal(v[2], v[0])
     mesh = rt.Mesh.from_obj(str(p), rt.Lambertian(rt.Color(.5, .5, .5)))
     assert rt.Scene(mesh, host_only=True).info().n_nodes == 3
+
+
+def _check_wide_tree(wn, leaf_points):
+    """Every child box (f32 and, when present, 8-bit) must contain what lies below it; every primitive
+    must be reachable exactly once.  leaf_points(ref) -> (k, 3) points the leaf box has to contain."""
+    seen = []
+
+    def contains(outer, inner):
+        return all(outer[2 * a] <= inner[2 * a] and outer[2 * a + 1] >= inner[2 * a + 1] for a in range(3))
+
+    def walk(i):
+        node = wn[i]
+        lo = np.full(3, np.inf)
+        hi = np.full(3, -np.inf)
+        for j in range(4):
+            ref = int(node["child"][j])
+            if ref == F.RT_REF_NONE:
+                continue
+            b32 = node["box32"][j]
+            if node["has_box8"]:
+                assert contains(node["box8"][j], b32), (i, j)
+            if ref >> 28 == F.RT_REF_NODE:
+                clo, chi = walk(ref & 0x0FFFFFFF)
+            else:
+                seen.append(ref)
+                pts = leaf_points(ref)
+                clo, chi = pts.min(axis=0), pts.max(axis=0)
+            inner = [clo[0], chi[0], clo[1], chi[1], clo[2], chi[2]]
+            assert contains(b32, inner), (i, j, b32, inner)
+            lo = np.minimum(lo, [b32[0], b32[2], b32[4]])
+            hi = np.maximum(hi, [b32[1], b32[3], b32[5]])
+        return lo, hi
+
+    walk(0)
+    return seen
+
+
+def test_wide_nodes_contain_their_children():
+    tris = scenes.triangle_soup(3000, seed=5)
+    desc = rt.SceneDesc.from_world(rt.Mesh(tris, rt.Lambertian(rt.Color(.5, .5, .5))))
+    wn = rt.Scene(desc, host_only=True).wide_nodes()
+    assert len(wn) > 500 and wn[0]["has_box8"] == 1  # similar-sized triangles: the 8-bit grid is accepted
+    seen = _check_wide_tree(wn, lambda ref: tris[ref & 0x0FFFFFFF])
+    assert sorted(seen) == [(F.RT_REF_TRI << 28) | i for i in range(3000)]
+    # on average the 8-bit boxes are only slightly larger than the f32 ones
+    valid = wn["child"] != F.RT_REF_NONE
+    d32 = wn["box32"][valid][:, 1::2] - wn["box32"][valid][:, 0::2]
+    d8 = wn["box8"][valid][:, 1::2] - wn["box8"][valid][:, 0::2]
+    assert np.all(d8 >= d32) and d8.sum() / d32.sum() < 1.05
+
+
+def test_wide_nodes_fall_back_to_f32_when_one_primitive_dwarfs_the_rest():
+    world, lights, cam = scenes.book1_final(seed=0)  # ground sphere of radius 1000 among spheres of radius 0.2
+    desc = rt.SceneDesc.from_world(world, lights)
+    wn = rt.Scene(desc, host_only=True).wide_nodes()
+    assert len(wn) > 100 and wn[0]["has_box8"] == 0
+    sph = desc.arrays["spheres"]
+
+    def pts(ref):
+        s = sph[ref & 0x0FFFFFFF]
+        c, r = np.array(s["center"]), s["radius"]
+        return np.stack([c - r, c + r])
+
+    seen = _check_wide_tree(wn, pts)
+    assert sorted(seen) == [(F.RT_REF_SPHERE << 28) | i for i in range(len(sph))]
+    # a world that is not one BVH over primitives has no wide nodes
+    world, lights, cam = scenes.cornell_box()
+    assert len(rt.Scene(rt.SceneDesc.from_world(world, lights), host_only=True).wide_nodes()) == 0
