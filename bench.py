@@ -142,7 +142,9 @@ def main() -> None:
                            "ref_order_nodes_per_ray": nodes_per_ray, "ref_order_prims_per_ray": prims_per_ray,
                            "alg_bytes_per_ray": bytes_per_ray, "count_sample_rays": m,
                            "actual_box_tests_per_ray": actual_nodes, "actual_prim_tests_per_ray": actual_prims,
-                           "actual_bytes_per_ray": (32 if args.mode == "ordered" else 64) * actual_nodes + TRI_BYTES * actual_prims + RAY_BYTES + HIT_BYTES}
+                           # ordered: 64-byte 4-wide nodes (16 B per child box tested), one 128-byte line per triangle
+                           "actual_bytes_per_ray": (16 * actual_nodes + 128 * actual_prims if args.mode == "ordered"
+                                                    else 64 * actual_nodes + 128 * actual_prims) + RAY_BYTES + HIT_BYTES}
         out["roofline"]["achieved_actual"] = out["roofline"]["actual_bytes_per_ray"] * n / (avg_ms * 1e-3) / 1e9
         if not args.no_cpu:
             threads = min(16, os.cpu_count() or 1)

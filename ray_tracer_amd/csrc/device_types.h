@@ -45,17 +45,15 @@ struct alignas(16) DQuad {     // 144 B (quad.rs:15-25 without the bbox)
 // The three vertices the intersector reads (triangle.rs:113-115): 72 bytes in a 128-byte slot, so a
 // triangle test fetches exactly one line from HBM (packed at 72 bytes every second record straddles two,
 // and the primitive-BVH kernel is bound by the number of lines it pulls through the fabric).
+// The unit normal and the material, read once per accepted hit, ride in the same line.
 struct alignas(128) DTri {
     double v0[3];
     double v1[3];
     double v2[3];
-    double _pad[7];
-};
-
-struct alignas(16) DTriAux {   // 32 B: read once per accepted hit
     double n[3];               // unit normal (triangle.rs:125)
     int32_t mat;
-    int32_t _pad;
+    int32_t _pad0;
+    double _pad[3];
 };
 
 typedef rt_bvh_node DNode;     // 64 B
@@ -136,7 +134,6 @@ struct DScene {
     const DSphere* spheres;
     const DQuad* quads;
     const DTri* tris;
-    const DTriAux* tri_aux;
     const DList* lists;
     const uint32_t* list_items;
     const DXform* xforms;

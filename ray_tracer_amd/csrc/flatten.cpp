@@ -254,15 +254,15 @@ struct Flattener {
             o.mat = s.mat; o._pad = 0;
         }
         f.tris.resize(d->n_triangles);
-        f.tri_aux.resize(d->n_triangles);
         for (uint64_t i = 0; i < d->n_triangles; ++i) { // triangle.rs:122-125
             const rt_triangle& s = d->triangles[i];
             if (!mat_ok(s.mat)) return fail(RT_E_INVALID, "triangle: material out of range");
             DTri& o = f.tris[i];
             V3 v0 = v3(s.v0), v1 = v3(s.v1), v2 = v3(s.v2);
             put(o.v0, v0); put(o.v1, v1); put(o.v2, v2);
-            put(f.tri_aux[i].n, unit3(cross3(sub(v1, v0), sub(v2, v0))));
-            f.tri_aux[i].mat = s.mat; f.tri_aux[i]._pad = 0;
+            put(o.n, unit3(cross3(sub(v1, v0), sub(v2, v0))));
+            o.mat = s.mat; o._pad0 = 0;
+            o._pad[0] = o._pad[1] = o._pad[2] = 0.0;
         }
         return RT_OK;
     }

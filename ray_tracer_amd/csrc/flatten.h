@@ -20,7 +20,6 @@ struct FlatScene {
     std::vector<DSphere> spheres;
     std::vector<DQuad> quads;
     std::vector<DTri> tris;
-    std::vector<DTriAux> tri_aux;
     std::vector<DList> lists;
     std::vector<uint32_t> list_items;
     std::vector<DXform> xforms;

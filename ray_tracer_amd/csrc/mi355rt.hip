@@ -385,7 +385,7 @@ void fill_host_dscene(rt_scene* s) {
     FlatScene& f = s->flat;
     DScene& d = s->dev;
     d.nodes = f.nodes.data(); d.wnodes = f.wnodes.data(); d.qnodes = f.qnodes.data(); d.cqnodes = f.cqnodes.data(); d.spheres = f.spheres.data(); d.quads = f.quads.data(); d.tris = f.tris.data();
-    d.tri_aux = f.tri_aux.data(); d.lists = f.lists.data(); d.list_items = f.list_items.data(); d.xforms = f.xforms.data();
+    d.lists = f.lists.data(); d.list_items = f.list_items.data(); d.xforms = f.xforms.data();
     d.media = f.media.data(); d.materials = f.materials.data(); d.textures = f.textures.data(); d.images = f.images.data();
     d.image_bytes = f.image_bytes.data(); d.perlins = f.perlins.data(); d.lights = f.lights.data();
     d.world = f.world; d.n_lights = f.n_lights; d.lights_is_list = f.lights_is_list; d._pad = 0;
@@ -407,7 +407,6 @@ int upload_scene(rt_scene* s) {
     if ((rc = upload(s, f.spheres, &d.spheres))) return rc;
     if ((rc = upload(s, f.quads, &d.quads))) return rc;
     if ((rc = upload(s, f.tris, &d.tris))) return rc;
-    if ((rc = upload(s, f.tri_aux, &d.tri_aux))) return rc;
     if ((rc = upload(s, f.lists, &d.lists))) return rc;
     if ((rc = upload(s, f.list_items, &d.list_items))) return rc;
     if ((rc = upload(s, f.xforms, &d.xforms))) return rc;

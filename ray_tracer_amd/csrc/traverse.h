@@ -259,9 +259,8 @@ RT_DEV void finalize(const DScene& S, const WorldRay& w, double time, const Best
         D3 s = o - v0;
         h.u = f * dot(s, hh);
         h.v = f * dot(d, cross(s, edge1));
-        const DTriAux ax = S.tri_aux[idx];
-        set_face_normal(h, d, d3(ax.n[0], ax.n[1], ax.n[2]));
-        h.mat = ax.mat;
+        set_face_normal(h, d, d3p(tp->n));
+        h.mat = tp->mat;
     } else { // constant medium (constant_medium.rs:96-101); u,v are not written by the reference
         const DMedium m = S.media[idx];
         h.normal = d3(1.0, 0.0, 0.0);
