@@ -38,17 +38,34 @@ struct CamD { // Camera after initialize() (camera.rs:30-42)
     int32_t _pad;
 };
 
-struct PathState { // structure-of-arrays over path slots, all in HBM
-    double *ox, *oy, *oz, *dx, *dy, *dz, *time; // current ray
-    double *bx, *by, *bz;                        // throughput
-    double *lx, *ly, *lz;                        // accumulated radiance
-    double* hit_t;
-    uint32_t* hit_ref;
-    int32_t* hit_ctx;
-    uint32_t* rng_index;
+// One path = one 128-byte line in HBM.  The queues permute the paths after the first bounce, so every
+// kernel gathers its paths by index: with one array per field that was seventeen 8-byte gathers (seventeen
+// lines) per path and bounce, with one record it is a single line read and written once per kernel.
+struct alignas(128) PathRec {
+    double o[3], d[3];  // current ray (ray.rs:5-9)
+    double time;
+    double beta[3];     // throughput
+    double L[3];        // accumulated radiance
+    double hit_t;       // result of the last extend
+    uint32_t hit_ref;
+    int32_t hit_ctx;
+    uint32_t rng_index; // draws taken so far from the path's stream
+    uint32_t _pad;
+};
+static_assert(sizeof(PathRec) == 128, "a path is one cache line");
+constexpr uint64_t PATH_DOUBLES = sizeof(PathRec) / sizeof(double);
+
+struct PathState {
+    PathRec* rec;
     uint32_t* queue[2];
     unsigned long long* counters;
 };
+
+// The world ray of path p as the traversal and the record completion read it (strided view of the records).
+__device__ __forceinline__ WorldRay path_ray(const PathState& ps, uint32_t p) {
+    const double* b = reinterpret_cast<const double*>(ps.rec);
+    return WorldRay{b + 0, b + 1, b + 2, b + 3, b + 4, b + 5, (uint64_t)p * PATH_DOUBLES};
+}
 
 struct BatchGeom { // which (pixel, stratum) a path slot stands for
     int32_t x0, y0, tw, th;        // tile origin and size
@@ -165,12 +182,15 @@ __global__ __launch_bounds__(BLOCK) void raygen_kernel(CamD cam, BatchGeom bg, P
     }
     D3 dir = pixel_sample - origin;
     double time = g.next();
-    ps.ox[p] = origin.x; ps.oy[p] = origin.y; ps.oz[p] = origin.z;
-    ps.dx[p] = dir.x; ps.dy[p] = dir.y; ps.dz[p] = dir.z;
-    ps.time[p] = time;
-    ps.bx[p] = 1.0; ps.by[p] = 1.0; ps.bz[p] = 1.0;
-    ps.lx[p] = 0.0; ps.ly[p] = 0.0; ps.lz[p] = 0.0;
-    ps.rng_index[p] = g.index;
+    PathRec rec;
+    rec.o[0] = origin.x; rec.o[1] = origin.y; rec.o[2] = origin.z;
+    rec.d[0] = dir.x; rec.d[1] = dir.y; rec.d[2] = dir.z;
+    rec.time = time;
+    rec.beta[0] = 1.0; rec.beta[1] = 1.0; rec.beta[2] = 1.0;
+    rec.L[0] = 0.0; rec.L[1] = 0.0; rec.L[2] = 0.0;
+    rec.hit_t = D_INF; rec.hit_ref = RT_REF_NONE; rec.hit_ctx = 0;
+    rec.rng_index = g.index; rec._pad = 0;
+    ps.rec[p] = rec;
     ps.queue[0][p] = p;
 }
 
@@ -187,26 +207,30 @@ __global__ __launch_bounds__(BLOCK) void extend_kernel(DScene S, PathState ps, i
         unsigned long long q = base + lane;
         if (q < n) {
             uint32_t p = queue[q];
-            WorldRay w{ps.ox, ps.oy, ps.oz, ps.dx, ps.dy, ps.dz, p};
+            PathRec* rec = ps.rec + p;
+            const WorldRay w = path_ray(ps, p);
             RayD r;
             ray_in_context(S, w, 0, r);
-            double time = ps.time[p];
+            double time = rec->time;
             Best b;
             b.t = D_INF; b.ref = RT_REF_NONE; b.ctx = 0;
             uint32_t s_local = p / bg.npix, pix = p - s_local * bg.npix;
             int32_t i = bg.x0 + (int32_t)(pix % (uint32_t)bg.tw);
             int32_t j = bg.y0 + (int32_t)(pix / (uint32_t)bg.tw);
-            Rng g{seed, 0u, (uint32_t)(j * image_width + i), (uint32_t)(bg.sample0 + (int32_t)s_local), ps.rng_index[p]};
+            Rng g{seed, 0u, (uint32_t)(j * image_width + i), (uint32_t)(bg.sample0 + (int32_t)s_local), rec->rng_index};
             traverse<true, false, true>(S, S.world, r, 0, w, time, 0.001, b, stk, 0, &g, nn, np); // Interval::new(0.001, INFINITY) (camera.rs:258)
-            ps.hit_t[p] = b.t;
-            ps.hit_ref[p] = b.ref;
-            ps.hit_ctx[p] = b.ctx;
-            ps.rng_index[p] = g.index;
+            rec->hit_t = b.t;
+            rec->hit_ref = b.ref;
+            rec->hit_ctx = b.ctx;
+            rec->rng_index = g.index;
         }
     }
 }
 
-__global__ __launch_bounds__(BLOCK) void shade_kernel(DScene S, CamD cam, PathState ps, int qsel, unsigned long long seed, BatchGeom bg, int last_bounce) {
+#ifndef SHADE_WAVES
+#define SHADE_WAVES 1
+#endif
+__global__ __launch_bounds__(BLOCK, SHADE_WAVES) void shade_kernel(DScene S, CamD cam, PathState ps, int qsel, unsigned long long seed, BatchGeom bg, int last_bounce) {
     const unsigned long long n = ps.counters[C_LIVE_IN];
     const uint32_t* qin = ps.queue[qsel];
     uint32_t* qout = ps.queue[qsel ^ 1];
@@ -220,22 +244,23 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(DScene S, CamD cam, PathSt
         uint32_t p = 0;
         if (q < n) {
             p = qin[q];
-            D3 beta = d3(ps.bx[p], ps.by[p], ps.bz[p]);
-            D3 L = d3(ps.lx[p], ps.ly[p], ps.lz[p]);
+            PathRec* rec = ps.rec + p;
+            D3 beta = d3p(rec->beta);
+            D3 L = d3p(rec->L);
             Best b;
-            b.t = ps.hit_t[p]; b.ref = ps.hit_ref[p]; b.ctx = ps.hit_ctx[p];
+            b.t = rec->hit_t; b.ref = rec->hit_ref; b.ctx = rec->hit_ctx;
             if (b.ref == RT_REF_NONE) { // camera.rs:258-260
                 L = L + beta * d3p(cam.background);
             } else {
-                WorldRay w{ps.ox, ps.oy, ps.oz, ps.dx, ps.dy, ps.dz, p};
-                double time = ps.time[p];
+                const WorldRay w = path_ray(ps, p);
+                double time = rec->time;
                 HitRec h;
                 finalize(S, w, time, b, h);
                 uint32_t s_local = p / bg.npix, pix = p - s_local * bg.npix;
                 int32_t i = bg.x0 + (int32_t)(pix % (uint32_t)bg.tw);
                 int32_t j = bg.y0 + (int32_t)(pix / (uint32_t)bg.tw);
-                Rng g{seed, 0u, (uint32_t)(j * cam.image_width + i), (uint32_t)(bg.sample0 + (int32_t)s_local), ps.rng_index[p]};
-                D3 ray_dir = d3(ps.dx[p], ps.dy[p], ps.dz[p]);
+                Rng g{seed, 0u, (uint32_t)(j * cam.image_width + i), (uint32_t)(bg.sample0 + (int32_t)s_local), rec->rng_index};
+                D3 ray_dir = d3p(rec->d);
                 D3 no, nd;
                 alive = shade_hit(S, h, ray_dir, g, beta, L, no, nd);
                 if (alive) {
@@ -243,14 +268,14 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(DScene S, CamD cam, PathSt
                         L = L + beta * d3(0.0, 0.0, 0.0);
                         alive = false;
                     } else {
-                        ps.ox[p] = no.x; ps.oy[p] = no.y; ps.oz[p] = no.z;
-                        ps.dx[p] = nd.x; ps.dy[p] = nd.y; ps.dz[p] = nd.z;
-                        ps.bx[p] = beta.x; ps.by[p] = beta.y; ps.bz[p] = beta.z;
-                        ps.rng_index[p] = g.index;
+                        rec->o[0] = no.x; rec->o[1] = no.y; rec->o[2] = no.z;
+                        rec->d[0] = nd.x; rec->d[1] = nd.y; rec->d[2] = nd.z;
+                        rec->beta[0] = beta.x; rec->beta[1] = beta.y; rec->beta[2] = beta.z;
+                        rec->rng_index = g.index;
                     }
                 }
             }
-            ps.lx[p] = L.x; ps.ly[p] = L.y; ps.lz[p] = L.z;
+            rec->L[0] = L.x; rec->L[1] = L.y; rec->L[2] = L.z;
         }
         // compact: surviving paths of this wave take consecutive slots of the next queue
         unsigned long long mask = __ballot(alive);
@@ -273,7 +298,8 @@ __global__ __launch_bounds__(BLOCK) void accumulate_kernel(PathState ps, BatchGe
     double r = a[0], g = a[1], b = a[2];
     for (int32_t s = 0; s < bg.nsamples; ++s) { // pixel_color += ray_color(...) in stratum order
         size_t p = (size_t)s * bg.npix + pix;
-        r += ps.lx[p]; g += ps.ly[p]; b += ps.lz[p];
+        const PathRec* rec = ps.rec + p;
+        r += rec->L[0]; g += rec->L[1]; b += rec->L[2];
     }
     a[0] = r; a[1] = g; a[2] = b;
 }
@@ -446,13 +472,8 @@ int ensure_workspace(rt_scene* s, uint64_t paths) {
         return RT_OK;
     };
     PathState& ps = s->ps;
-    double** dbl[] = {&ps.ox, &ps.oy, &ps.oz, &ps.dx, &ps.dy, &ps.dz, &ps.time, &ps.bx, &ps.by, &ps.bz, &ps.lx, &ps.ly, &ps.lz, &ps.hit_t};
     int rc;
-    for (double** a : dbl)
-        if ((rc = alloc(reinterpret_cast<void**>(a), paths * sizeof(double)))) return rc;
-    if ((rc = alloc(reinterpret_cast<void**>(&ps.hit_ref), paths * sizeof(uint32_t)))) return rc;
-    if ((rc = alloc(reinterpret_cast<void**>(&ps.hit_ctx), paths * sizeof(int32_t)))) return rc;
-    if ((rc = alloc(reinterpret_cast<void**>(&ps.rng_index), paths * sizeof(uint32_t)))) return rc;
+    if ((rc = alloc(reinterpret_cast<void**>(&ps.rec), paths * sizeof(PathRec)))) return rc;
     if ((rc = alloc(reinterpret_cast<void**>(&ps.queue[0]), paths * sizeof(uint32_t)))) return rc;
     if ((rc = alloc(reinterpret_cast<void**>(&ps.queue[1]), paths * sizeof(uint32_t)))) return rc;
     ps.counters = s->d_counters;

@@ -45,6 +45,7 @@ RT_DEV double perlin_turb(const rt_perlin* t, D3 p, int depth) { // perlin.rs:13
     double accum = 0.0;
     D3 temp_p = p;
     double weight = 1.0;
+#pragma unroll 1
     for (int i = 0; i < depth; ++i) {
         accum += weight * perlin_noise(t, temp_p);
         weight *= 0.5;
