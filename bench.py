@@ -146,6 +146,10 @@ def main() -> None:
                            "actual_bytes_per_ray": (16 * actual_nodes + 128 * actual_prims if args.mode == "ordered"
                                                     else 64 * actual_nodes + 128 * actual_prims) + RAY_BYTES + HIT_BYTES}
         out["roofline"]["achieved_actual"] = out["roofline"]["actual_bytes_per_ray"] * n / (avg_ms * 1e-3) / 1e9
+        if out["roofline"]["traffic"]:
+            # measured L2 <-> fabric bytes per launch (profiles/) over this run's kernel time: the binding roof
+            out["roofline"]["traffic_gbs"] = out["roofline"]["traffic"] / (avg_ms * 1e-3) / 1e9
+            out["roofline"]["traffic_frac"] = out["roofline"]["traffic_gbs"] / HBM_PEAK_GBS
         if not args.no_cpu:
             threads = min(16, os.cpu_count() or 1)
             mc = min(args.cpu_sample, n)

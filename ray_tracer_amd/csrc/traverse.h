@@ -84,6 +84,24 @@ RT_DEV void load_wnode(const WNode* wnodes, uint32_t idx, WNodeLoad& n) {
     n.left = d.x; n.right = d.y; n.meta = d.z; n.pad = d.w;
 }
 
+// One primitive against the lane's ray over (tmin, best.t]; a closer hit replaces `best`.
+RT_DEV void test_primitive(const DScene& S, uint32_t ref, const RayD& ray, int32_t ctx, double time, double tmin, Best& best) {
+    const uint32_t kind = ref >> 28, idx = ref & 0x0FFFFFFFu;
+    if (kind == RT_REF_TRI) {
+        const DTri* tp = S.tris + idx;
+        double t, u, v;
+        if (tri_test(d3p(tp->v0), d3p(tp->v1), d3p(tp->v2), ray, tmin, best.t, t, u, v)) { best.t = t; best.ref = ref; best.ctx = ctx; }
+    } else if (kind == RT_REF_SPHERE) {
+        const DSphere s = S.spheres[idx];
+        double t;
+        if (sphere_test(s, ray, time, tmin, best.t, t)) { best.t = t; best.ref = ref; best.ctx = ctx; }
+    } else { // RT_REF_QUAD
+        const DQuad* q = S.quads + idx;
+        double t, al, be;
+        if (quad_test(*q, ray, tmin, best.t, t, al, be)) { best.t = t; best.ref = ref; best.ctx = ctx; }
+    }
+}
+
 // Closest hit of `root` for the lane's ray over (tmin, best.t].  TOP = the world query
 // (constant media allowed); the nested boundary queries of a medium run with TOP = false.
 // `stk` points at this lane's column of the LDS stack, entries are BLOCK words apart.
@@ -135,32 +153,32 @@ __device__ __forceinline__ void traverse(const DScene& S, uint32_t root, RayD ra
                 cur = n.left;
                 pop = false;
             }
-        } else if (kind == RT_REF_TRI) {
-            const DTri* tp = S.tris + idx;
+        } else if (kind == RT_REF_TRI || kind == RT_REF_SPHERE || kind == RT_REF_QUAD) {
             if (COUNT) ++n_prims;
-            double t, u, v;
-            if (tri_test(d3p(tp->v0), d3p(tp->v1), d3p(tp->v2), ray, tmin, best.t, t, u, v)) { best.t = t; best.ref = cur; best.ctx = ctx; }
-        } else if (kind == RT_REF_SPHERE) {
-            const DSphere s = S.spheres[idx];
-            if (COUNT) ++n_prims;
-            double t;
-            if (sphere_test(s, ray, time, tmin, best.t, t)) { best.t = t; best.ref = cur; best.ctx = ctx; }
-        } else if (kind == RT_REF_QUAD) {
-            const DQuad* q = S.quads + idx;
-            if (COUNT) ++n_prims;
-            double t, al, be;
-            if (quad_test(*q, ray, tmin, best.t, t, al, be)) { best.t = t; best.ref = cur; best.ctx = ctx; }
+            test_primitive(S, cur, ray, ctx, time, tmin, best);
         } else if (kind == RT_REF_LIST || kind == REF_LISTCONT) {
             uint32_t pos = 0;
             if (kind == REF_LISTCONT) { --sp; pos = stk[sp * BLOCK]; }
             const DList l = S.lists[idx];
-            if (pos < l.count) {
+            // Items are visited in list order (hittable_list.rs:46-57).  Primitives are tested right here;
+            // the first item that is something else is entered through the stack, with the rest of the
+            // list left behind as a continuation.
+            while (pos < l.count) {
+                const uint32_t item = S.list_items[l.first + pos];
+                const uint32_t ik = item >> 28;
+                if (ik == RT_REF_TRI || ik == RT_REF_SPHERE || ik == RT_REF_QUAD) {
+                    if (COUNT) ++n_prims;
+                    test_primitive(S, item, ray, ctx, time, tmin, best);
+                    ++pos;
+                    continue;
+                }
                 if (pos + 1 < l.count) {
                     stk[sp * BLOCK] = pos + 1; ++sp;
                     stk[sp * BLOCK] = make_ref(REF_LISTCONT, idx); ++sp;
                 }
-                cur = S.list_items[l.first + pos];
+                cur = item;
                 pop = false;
+                break;
             }
         } else if (kind == RT_REF_XFORM) {
             const DXform x = S.xforms[idx];
