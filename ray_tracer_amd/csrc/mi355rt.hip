@@ -504,7 +504,7 @@ int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit
         const uint64_t waves_launched = (uint64_t)fblocks * (FAST_BLOCK / 64);
         const int chunk = env_int("MI355RT_CHUNK", (int)std::max<uint64_t>(16, std::min<uint64_t>(128, n / (waves_launched * 8))));
         auto flaunch = [&](auto kernel) {
-            hipLaunchKernelGGL(kernel, dim3(fblocks), dim3(FAST_BLOCK), (size_t)env_int("MI355RT_DYNLDS", 0), st, s->dev, s->flat.fast_root, *rays, (unsigned long long)n, rq, opt, 0.001,
+            hipLaunchKernelGGL(kernel, dim3(fblocks), dim3(FAST_BLOCK), 0, st, s->dev, s->flat.fast_root, *rays, (unsigned long long)n, rq, opt, 0.001,
                                s->fast_extent, hits->t, hits->prim, s->d_counters + C_WORK, s->d_counters + C_NODES, s->fast_spill,
                                env_int("MI355RT_REFILL", REFILL_THRESHOLD), env_int("MI355RT_VOTE", LEAF_VOTE), chunk, env_int("MI355RT_POP_TRIPS", POP_TRIPS));
         };
