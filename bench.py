@@ -159,6 +159,12 @@ def main() -> None:
             out["cpu_baseline"] = {"value": mc / cpu_s / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
                                    "sample": f"first {mc} rays of the same batch, C++ f64 restatement of the reference "
                                              f"(reference-order traversal), {threads} threads, {cpu_s:.1f} s"}
+            # the same restatement on one core, on a smaller slice of the batch
+            m1 = min(mc, max(1, mc // 16))
+            t1 = time.perf_counter()
+            cpu.closest_hit(o[:m1], d[:m1], time=tm[:m1], nthreads=1)
+            one_s = time.perf_counter() - t1
+            out["cpu_baseline"]["single_thread"] = {"value": m1 / one_s / 1e6, "unit": "Mrays/s", "sample": f"first {m1} rays, {one_s:.1f} s"}
             got = hits["prim"][:mc].cpu().numpy().astype(np.uint32)
             same = got == ref["prim"]
             t_gpu = hits["t"][:mc].cpu().numpy()

@@ -35,7 +35,7 @@ def main() -> None:
     from ray_tracer_amd import _ffi as F
     from ray_tracer_amd import scenes
 
-    build = {"cornell": scenes.cornell_box, "book1": scenes.book1_final, "book2": scenes.book2_final,
+    build = {"cornell": scenes.cornell_box, "book1": scenes.book1_final, "book2": scenes.book2_final, "mesh_spheres": scenes.mesh_and_spheres,
              "smoke": scenes.cornell_smoke}[args.scene]
     world, lights, cam = build()
     if args.spp:

@@ -279,6 +279,21 @@ def test_triangle() -> SceneTuple:  # main.rs:864-895
     return world, None, _sky_camera(80.0, Point3(0.0, 0.0, 9.0), Point3(0.0, 0.0, 0.0), aspect=1.0)
 
 
+def mesh_and_spheres(seed: int = 0, subdiv: int = 6, image_width: int = 4096, samples_per_pixel: int = 4096,
+                     max_depth: int = 50) -> SceneTuple:
+    """The multi-GPU frame of the measurement plan: the Book-1 sphere field (BVH, main.rs:99-180) around
+    a bunny-class closed mesh (Mesh = BVH over triangles, mesh.rs:163) standing on the ground, lit by
+    the sky background.  4096 x 2304 at 4096 spp by default; tests render it small."""
+    world_bvh, _, cam = book1_final(seed=seed)
+    tris = icosphere_mesh(subdiv, seed=4) * 3.0 + np.array([-1.5, 0.1, -3.5])  # radius ~1.2, centre (0, 1.6, -2)
+    world = HittableList()
+    world.add(world_bvh.objects[0])
+    world.add(Mesh(tris, Metal(Color(0.8, 0.8, 0.9), 0.05)))
+    cam.image_width, cam.samples_per_pixel, cam.max_depth = image_width, samples_per_pixel, max_depth
+    cam.lookat = Point3(0.0, 0.8, -1.0)
+    return world, None, cam
+
+
 # ------------------------------------------------------------------ synthetic workloads
 def _philox_uniform(n: int, seed: int, dims: int) -> np.ndarray:
     """(n, dims) uniforms in [0,1) from numpy's Philox bit generator (fast bulk stream for

@@ -86,6 +86,21 @@ def test_texture_scenes():
         check(c, a, b)
 
 
+def test_mesh_and_spheres_frame_and_its_partition():
+    """The multi-GPU frame (sphere BVH + triangle-mesh BVH in one list, metal mesh): parity with the oracle, and
+    the per-rank (tile, stratum-range) units of an 8-way partition add up to the unsplit frame."""
+    from ray_tracer_amd import parallel
+    cam, c, a, b, stats, ctr, gpu = render_both(scenes.mesh_and_spheres, 96, 16, 12, seed=8, subdiv=3)
+    check(c, a, b)
+    assert ctr.render_rays == stats["rays"]
+    d = O.camera_initialize(c)
+    acc = np.zeros_like(a)
+    for rank in range(8):
+        for w in parallel.partition_frame(c.image_width, d.image_height, d.sqrt_spp * d.sqrt_spp, rank, 8):
+            gpu.render(c, seed=8, work=w, accum=acc)
+    assert np.allclose(acc, a, rtol=1e-12, atol=1e-12, equal_nan=True)
+
+
 def test_partition_independence_and_accumulation():
     """The frame split by tile and by stratum range must reproduce the unsplit frame (the streams are
     keyed by pixel and stratum); batches smaller than the frame must not change it either."""
