@@ -85,6 +85,10 @@ struct RayQueue {              // optional indirection: ray i of the launch is p
     const unsigned long long* count; // nullptr: use n
 };
 
+// RS = element stride of the batch arrays: 1 for the structure-of-arrays batches of the C ABI.  The
+// renderer hands in strided views of its 128-byte path records instead of copying rays out of them
+// (RS = doubles per record; out_t shares that stride, out_prim counts 32-bit words: 2 * RS).
+
 constexpr int LDS_STACK = 8;   // stack entries per lane held in LDS (power of two); deeper ones spill to HBM
 constexpr int FAST_WAVES = FAST_BLOCK / 64;
 constexpr uint32_t NO_NODE = 0xFFFFFFFFu;
@@ -141,13 +145,14 @@ RT_DEV void order2(float& ka, uint32_t& ra, float& kb, uint32_t& rb) { // ascend
 RT_DEV float ubyte_f32(uint32_t w, int byte) { return (float)((w >> (8 * byte)) & 0xFFu); } // v_cvt_f32_ubyteN
 
 // PRIM: RT_REF_TRI / RT_REF_SPHERE / RT_REF_QUAD when every leaf has that kind, 0 for mixed leaves.
-template <int PRIM, bool COUNT, bool QUANT>
+template <int PRIM, bool COUNT, bool QUANT, int RS>
 __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, uint32_t root, rt_ray_batch rays,
                                                                        unsigned long long n_in, RayQueue rq, uint32_t opt, double tmin_default,
                                                                        float scene_extent, double* out_t, uint32_t* out_prim,
                                                                        unsigned long long* work_counter,
                                                                        unsigned long long* stat_counters, uint2* spill, int refill_threshold,
-                                                                       int leaf_vote, int chunk, int pop_trips) {
+                                                                       int leaf_vote, int chunk_in, int pop_trips) {
+    constexpr unsigned long long OUT_T_STRIDE = RS, OUT_PRIM_STRIDE = RS == 1 ? 1 : 2 * RS;
     __shared__ uint2 s_fast_stack[LDS_STACK * FAST_BLOCK];
     LaneStack st;
     st.spill_stride = (size_t)gridDim.x * FAST_BLOCK;
@@ -156,6 +161,13 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, 
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lane_below = (1ull << lane) - 1ull;
     const unsigned long long n = rq.count ? *rq.count : n_in;
+    // rays a wave takes from the global counter at a time: large enough to make the counter cheap, small
+    // enough that every launched wave gets several chunks (chunk_in > 0 overrides, for measurements)
+    int chunk = chunk_in;
+    if (chunk <= 0) {
+        const unsigned long long per = n / ((unsigned long long)gridDim.x * FAST_WAVES * 8ull);
+        chunk = per < 16ull ? 16 : (per > 128ull ? 128 : (int)per);
+    }
     const char* const qbase = QUANT ? reinterpret_cast<const char*>(S.cqnodes) : reinterpret_cast<const char*>(S.qnodes);
 
     bool active = false;
@@ -199,13 +211,14 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, 
                     const unsigned long long qi = wave_next + (unsigned long long)__popcll(idle & lane_below);
                     if (qi < wave_end) {
                         const unsigned long long i = rq.queue ? (unsigned long long)rq.queue[qi] : qi;
-                        r.ox = rays.ox[i]; r.oy = rays.oy[i]; r.oz = rays.oz[i];
-                        r.dx = rays.dx[i]; r.dy = rays.dy[i]; r.dz = rays.dz[i];
+                        const unsigned long long ri = i * (unsigned long long)RS;
+                        r.ox = rays.ox[ri]; r.oy = rays.oy[ri]; r.oz = rays.oz[ri];
+                        r.dx = rays.dx[ri]; r.dy = rays.dy[ri]; r.dz = rays.dz[ri];
                         make_ray32(r, scene_extent, q);
                         // which optional arrays exist is decided on the host (opt bits 0/1/2 = time/tmin/tmax)
-                        time = (opt & 1u) ? rays.time[i] : 0.0;
-                        tmin = (opt & 2u) ? rays.tmin[i] : tmin_default;
-                        best_t = (opt & 4u) ? rays.tmax[i] : D_INF;
+                        time = (opt & 1u) ? rays.time[ri] : 0.0;
+                        tmin = (opt & 2u) ? rays.tmin[ri] : tmin_default;
+                        best_t = (opt & 4u) ? rays.tmax[ri] : D_INF;
                         tmin32 = f32_round_down(tmin);
                         best32 = f32_round_up(best_t);
                         best_ref = RT_REF_NONE;
@@ -342,8 +355,8 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, 
                 // loop with one or two lanes working, so the rest is left for the following iterations.
                 for (int trip = 0; trip < pop_trips; ++trip) {
                     if (st.sp == 0) {
-                        out_t[ray_slot] = best_ref == RT_REF_NONE ? D_INF : best_t;
-                        out_prim[ray_slot] = best_ref;
+                        out_t[ray_slot * OUT_T_STRIDE] = best_ref == RT_REF_NONE ? D_INF : best_t;
+                        out_prim[ray_slot * OUT_PRIM_STRIDE] = best_ref;
                         active = false;
                         pop = false;
                         break;

@@ -360,14 +360,17 @@ int upload(rt_scene* s, const std::vector<T>& v, const T** out) {
 
 using FastKernel = void (*)(DScene, uint32_t, rt_ray_batch, unsigned long long, RayQueue, uint32_t, double, float, double*, uint32_t*,
                             unsigned long long*, unsigned long long*, uint2*, int, int, int, int);
-template <bool COUNT, bool QUANT> FastKernel fast_kernel_for(int prim) {
-    if (prim == (int)RT_REF_TRI) return bvh4_closest_hit_kernel<RT_REF_TRI, COUNT, QUANT>;
-    if (prim == (int)RT_REF_SPHERE) return bvh4_closest_hit_kernel<RT_REF_SPHERE, COUNT, QUANT>;
-    return bvh4_closest_hit_kernel<0, COUNT, QUANT>;
+template <bool COUNT, bool QUANT, int RS> FastKernel fast_kernel_for(int prim) {
+    if (prim == (int)RT_REF_TRI) return bvh4_closest_hit_kernel<RT_REF_TRI, COUNT, QUANT, RS>;
+    if (prim == (int)RT_REF_SPHERE) return bvh4_closest_hit_kernel<RT_REF_SPHERE, COUNT, QUANT, RS>;
+    return bvh4_closest_hit_kernel<0, COUNT, QUANT, RS>;
 }
-FastKernel fast_kernel(int prim, bool count, bool quant) {
-    if (quant) return count ? fast_kernel_for<true, true>(prim) : fast_kernel_for<false, true>(prim);
-    return count ? fast_kernel_for<true, false>(prim) : fast_kernel_for<false, false>(prim);
+FastKernel fast_kernel(int prim, bool count, bool quant) { // structure-of-arrays batches of the C ABI
+    if (quant) return count ? fast_kernel_for<true, true, 1>(prim) : fast_kernel_for<false, true, 1>(prim);
+    return count ? fast_kernel_for<true, false, 1>(prim) : fast_kernel_for<false, false, 1>(prim);
+}
+FastKernel fast_kernel_paths(int prim, bool quant) { // strided views of the renderer's path records
+    return quant ? fast_kernel_for<false, true, (int)PATH_DOUBLES>(prim) : fast_kernel_for<false, false, (int)PATH_DOUBLES>(prim);
 }
 int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
@@ -484,7 +487,7 @@ int ensure_workspace(rt_scene* s, uint64_t paths) {
 uint64_t max_paths_setting() {
     const char* e = getenv("MI355RT_MAX_PATHS");
     if (e) { long long v = atoll(e); if (v >= 1024) return (uint64_t)v; }
-    return 1ull << 22;
+    return 1ull << 24;
 }
 
 int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit_batch* hits, uint64_t seed, uint32_t flags, hipStream_t st) {
@@ -499,14 +502,11 @@ int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit
         int fblocks = (int)std::min<uint64_t>((uint64_t)s->fast_grid_blocks, (waves + (FAST_BLOCK / 64) - 1) / (FAST_BLOCK / 64));
         RayQueue rq{nullptr, nullptr};
         const uint32_t opt = (rays->time ? 1u : 0u) | (rays->tmin ? 2u : 0u) | (rays->tmax ? 4u : 0u);
-        // rays a wave takes from the global counter at a time: large enough to make the counter cheap, small
-        // enough that every launched wave gets several chunks
-        const uint64_t waves_launched = (uint64_t)fblocks * (FAST_BLOCK / 64);
-        const int chunk = env_int("MI355RT_CHUNK", (int)std::max<uint64_t>(16, std::min<uint64_t>(128, n / (waves_launched * 8))));
         auto flaunch = [&](auto kernel) {
             hipLaunchKernelGGL(kernel, dim3(fblocks), dim3(FAST_BLOCK), 0, st, s->dev, s->flat.fast_root, *rays, (unsigned long long)n, rq, opt, 0.001,
                                s->fast_extent, hits->t, hits->prim, s->d_counters + C_WORK, s->d_counters + C_NODES, s->fast_spill,
-                               env_int("MI355RT_REFILL", REFILL_THRESHOLD), env_int("MI355RT_VOTE", LEAF_VOTE), chunk, env_int("MI355RT_POP_TRIPS", POP_TRIPS));
+                               env_int("MI355RT_REFILL", REFILL_THRESHOLD), env_int("MI355RT_VOTE", LEAF_VOTE), env_int("MI355RT_CHUNK", 0),
+                               env_int("MI355RT_POP_TRIPS", POP_TRIPS));
         };
         flaunch(fast_kernel(s->fast_prim, count, s->fast_quant));
         HIP_TRY(hipGetLastError());
@@ -572,10 +572,28 @@ int render_impl(rt_scene* s, const rt_camera* cam, uint64_t seed, const rt_work*
             s->counters.paths += bg.npaths;
             int qsel = 0;
             uint64_t live = bg.npaths;
+            // MI355RT_FAST_EXTEND=0 keeps the general traversal for BVH-only worlds (A/B measurements)
+            const bool fast_extend = s->flat.fast_root != RT_REF_NONE && env_int("MI355RT_FAST_EXTEND", 1) != 0;
             for (int32_t bounce = 0; bounce < cam->max_depth && live > 0; ++bounce) {
                 uint64_t waves = (live + 63) / 64;
                 int blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)s->grid_blocks, (waves + (BLOCK / 64) - 1) / (BLOCK / 64)));
-                hipLaunchKernelGGL(extend_kernel, dim3(blocks), dim3(BLOCK), 0, st, s->dev, ps, qsel, (unsigned long long)seed, bg, cam->image_width);
+                if (fast_extend) {
+                    // the world is one BVH over primitives: the primitive-BVH kernel reads the rays straight out of
+                    // the path records (strided views) and writes hit_t / hit_ref back into them; no transforms and
+                    // no media on this path, so hit_ctx (0 since raygen) and the RNG index are left alone
+                    const double* rb = reinterpret_cast<const double*>(ps.rec);
+                    rt_ray_batch view{rb + 0, rb + 1, rb + 2, rb + 3, rb + 4, rb + 5, rb + 6, nullptr, nullptr};
+                    RayQueue rq{ps.queue[qsel], s->d_counters + C_LIVE_IN};
+                    double* out_t = reinterpret_cast<double*>(ps.rec) + offsetof(PathRec, hit_t) / sizeof(double);
+                    uint32_t* out_prim = reinterpret_cast<uint32_t*>(ps.rec) + offsetof(PathRec, hit_ref) / sizeof(uint32_t);
+                    int fblocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)s->fast_grid_blocks, (waves + (FAST_BLOCK / 64) - 1) / (FAST_BLOCK / 64)));
+                    hipLaunchKernelGGL(fast_kernel_paths(s->fast_prim, s->fast_quant), dim3(fblocks), dim3(FAST_BLOCK), 0, st, s->dev, s->flat.fast_root,
+                                       view, (unsigned long long)live, rq, 1u, 0.001, s->fast_extent, out_t, out_prim, s->d_counters + C_WORK,
+                                       s->d_counters + C_NODES, s->fast_spill, env_int("MI355RT_REFILL", REFILL_THRESHOLD),
+                                       env_int("MI355RT_VOTE", LEAF_VOTE), env_int("MI355RT_CHUNK", 0), env_int("MI355RT_POP_TRIPS", POP_TRIPS));
+                } else {
+                    hipLaunchKernelGGL(extend_kernel, dim3(blocks), dim3(BLOCK), 0, st, s->dev, ps, qsel, (unsigned long long)seed, bg, cam->image_width);
+                }
                 hipLaunchKernelGGL(shade_kernel, dim3(blocks), dim3(BLOCK), 0, st, s->dev, cd, ps, qsel, (unsigned long long)seed, bg, bounce == cam->max_depth - 1 ? 1 : 0);
                 hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, st, s->d_counters);
                 s->counters.extend_launches += 1;
