@@ -29,35 +29,6 @@ constexpr int REFILL_THRESHOLD = 40; // refill when fewer lanes than this are st
 constexpr int POP_TRIPS = 2;         // stack entries a lane may take (and discard) per iteration
 constexpr int LEAF_VOTE = 24;        // lanes that must stand on a primitive before the wave runs the intersector
 
-// Conservative f32 slab test of the fast kernel.  For one axis the entry / exit parameters of the
-// slab [b0, b1] are  t = b * inv + c  with c = -(o * inv)  (one fused multiply-add per plane; the
-// fusion only concerns this culling test, never a value that is reported).  With inv and c rounded
-// to f32 the computed t is within 2^-23 * |inv| * (|b| + |o|) of the exact one, so the near
-// parameter is lowered and the far one raised by  E = 2^-21 * |inv| * (M + |o|),  M = largest
-// |coordinate| of the BVH: the f32 test accepts every box the exact f64 test accepts.  A NaN
-// (0 * inf) is dropped by fmin/fmax, which leaves that axis unconstrained (accepting).
-struct Ray32 {
-    float inv[3];  // 1/d
-    float cn[3];   // c - E
-    float cf[3];   // c + E
-    bool neg[3];   // d < 0: the box max is the entry plane
-};
-
-RT_DEV void make_ray32(const RayD& r, float scene_extent, Ray32& q) {
-    const double o[3] = {r.ox, r.oy, r.oz}, d[3] = {r.dx, r.dy, r.dz};
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const double inv = 1.0 / d[k];
-        const float inv32 = (float)inv;
-        const float c = (float)(-(o[k] * inv));
-        const float e = 4.76837158203125e-07f * fabsf(inv32) * (scene_extent + fabsf((float)o[k])); // 2^-21
-        q.inv[k] = inv32;
-        q.cn[k] = c - e;
-        q.cf[k] = c + e;
-        q.neg[k] = d[k] < 0.0;
-    }
-}
-
 RT_DEV bool slab32(const float* b, const Ray32& q, float tmin_lo, float best_hi, float& near_t) {
     const float nx = q.neg[0] ? b[1] : b[0], fx = q.neg[0] ? b[0] : b[1];
     const float ny = q.neg[1] ? b[3] : b[2], fy = q.neg[1] ? b[2] : b[3];
@@ -69,15 +40,6 @@ RT_DEV bool slab32(const float* b, const Ray32& q, float tmin_lo, float best_hi,
     const float tf = fminf(fminf(tfx, tfy), fminf(tfz, best_hi));
     near_t = tn;
     return tn <= tf;
-}
-
-RT_DEV float f32_round_up(double x) { // smallest float >= x
-    float f = (float)x;
-    return ((double)f < x) ? __uint_as_float(__float_as_uint(f) + (f >= 0.0f ? 1u : 0xFFFFFFFFu)) : f;
-}
-RT_DEV float f32_round_down(double x) { // largest float <= x
-    float f = (float)x;
-    return ((double)f > x) ? __uint_as_float(__float_as_uint(f) + (f > 0.0f ? 0xFFFFFFFFu : 1u)) : f;
 }
 
 struct RayQueue {              // optional indirection: ray i of the launch is path queue[i]
@@ -129,12 +91,6 @@ struct LaneStack {
         if ((st).sp < (st).base) { (st).base = (st).sp; (out) = (st).spill[(size_t)(st).sp * (st).spill_stride]; } \
     } while (0)
 
-RT_DEV void order2(float& ka, uint32_t& ra, float& kb, uint32_t& rb) { // ascending by key
-    const bool sw = kb < ka;
-    const float k0 = sw ? kb : ka, k1 = sw ? ka : kb;
-    const uint32_t r0 = sw ? rb : ra, r1 = sw ? ra : rb;
-    ka = k0; kb = k1; ra = r0; rb = r1;
-}
 
 // Node fetch: each lane reads its own node.  A cooperative variant (the eight lanes of a group read
 // the eight 16-byte pieces of one node in a single instruction, nodes handed to their owners through
@@ -214,6 +170,7 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, 
                         const unsigned long long ri = i * (unsigned long long)RS;
                         r.ox = rays.ox[ri]; r.oy = rays.oy[ri]; r.oz = rays.oz[ri];
                         r.dx = rays.dx[ri]; r.dy = rays.dy[ri]; r.dz = rays.dz[ri];
+                        set_inverse(r);
                         make_ray32(r, scene_extent, q);
                         // which optional arrays exist is decided on the host (opt bits 0/1/2 = time/tmin/tmax)
                         time = (opt & 1u) ? rays.time[ri] : 0.0;
@@ -243,7 +200,7 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, 
             // lane still running), (3) lanes whose node missed or whose primitive was tested pop.
             // Holding primitive tests back until a quorum is reached keeps the f64 intersector from
             // running with a handful of lanes while the rest of the wave waits.
-            const bool at_node = active && !pop && (cur >> 28) == RT_REF_NODE;
+            const bool at_node = active && !pop && (cur >> 28) == REF_QNODE;
             if (COUNT) { ++d_iters; d_run_lanes += __popcll(__ballot(active)); d_node_lanes += __popcll(__ballot(at_node)); }
             if (at_node) {
                 uint4 ch;
@@ -306,11 +263,11 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, 
                 }
                 if (nh > 0) {
                     // ascending by entry distance; misses (+inf) sink to the end
-                    order2(key[0], rf[0], key[1], rf[1]);
-                    order2(key[2], rf[2], key[3], rf[3]);
-                    order2(key[0], rf[0], key[2], rf[2]);
-                    order2(key[1], rf[1], key[3], rf[3]);
-                    order2(key[1], rf[1], key[2], rf[2]);
+                    sort2(key[0], rf[0], key[1], rf[1]);
+                    sort2(key[2], rf[2], key[3], rf[3]);
+                    sort2(key[0], rf[0], key[2], rf[2]);
+                    sort2(key[1], rf[1], key[3], rf[3]);
+                    sort2(key[1], rf[1], key[2], rf[2]);
                     if (nh > 3) RT_STACK_PUSH(st, rf[3], key[3]);
                     if (nh > 2) RT_STACK_PUSH(st, rf[2], key[2]);
                     if (nh > 1) RT_STACK_PUSH(st, rf[1], key[1]);
@@ -321,7 +278,7 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, 
             }
             RT_TICK(c_node);
             {
-                const bool at_leaf = active && !pop && (cur >> 28) != RT_REF_NODE;
+                const bool at_leaf = active && !pop && (cur >> 28) != REF_QNODE;
                 const unsigned long long leaf_mask = __ballot(at_leaf);
                 const unsigned long long run_mask = __ballot(active);
                 const bool quorum = __popcll(leaf_mask) >= leaf_vote || leaf_mask == run_mask;

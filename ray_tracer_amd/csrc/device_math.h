@@ -133,6 +133,45 @@ struct RayD { // a ray in the coordinates of the current transform context
 };
 RT_DEV void set_inverse(RayD& r) { r.ix = 1.0 / r.dx; r.iy = 1.0 / r.dy; r.iz = 1.0 / r.dz; }
 
+// Conservative f32 slab test of the 4-wide nodes.  For one axis the entry / exit parameters of the
+// slab [b0, b1] are  t = b * inv + c  with c = -(o * inv)  (one fused multiply-add per plane; the
+// fusion only concerns this culling test, never a value that is reported).  With inv and c rounded
+// to f32 the computed t is within 2^-23 * |inv| * (|b| + |o|) of the exact one, so the near
+// parameter is lowered and the far one raised by  E = 2^-21 * |inv| * (M + |o|),  M = largest
+// |coordinate| of the BVH: the f32 test accepts every box the exact f64 test accepts.  A NaN
+// (0 * inf) is dropped by fmin/fmax, which leaves that axis unconstrained (accepting).
+struct Ray32 {
+    float inv[3];  // 1/d
+    float cn[3];   // c - E
+    float cf[3];   // c + E
+    bool neg[3];   // d < 0: the box max is the entry plane
+};
+
+RT_DEV void make_ray32(const RayD& r, float scene_extent, Ray32& q) { // needs r.ix, r.iy, r.iz (set_inverse)
+    const double o[3] = {r.ox, r.oy, r.oz}, d[3] = {r.dx, r.dy, r.dz}, iv[3] = {r.ix, r.iy, r.iz};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double inv = iv[k];
+        const float inv32 = (float)inv;
+        const float c = (float)(-(o[k] * inv));
+        const float e = 4.76837158203125e-07f * fabsf(inv32) * (scene_extent + fabsf((float)o[k])); // 2^-21
+        q.inv[k] = inv32;
+        q.cn[k] = c - e;
+        q.cf[k] = c + e;
+        q.neg[k] = d[k] < 0.0;
+    }
+}
+
+RT_DEV float f32_round_up(double x) { // smallest float >= x
+    float f = (float)x;
+    return ((double)f < x) ? __uint_as_float(__float_as_uint(f) + (f >= 0.0f ? 1u : 0xFFFFFFFFu)) : f;
+}
+RT_DEV float f32_round_down(double x) { // largest float <= x
+    float f = (float)x;
+    return ((double)f > x) ? __uint_as_float(__float_as_uint(f) + (f > 0.0f ? 0xFFFFFFFFu : 1u)) : f;
+}
+
+
 // Aabb::hit (aabb.rs:82-107) on bounds = xmin xmax ymin ymax zmin zmax.
 RT_DEV bool slab_test(const double* b, const RayD& r, double lo, double hi) {
     {

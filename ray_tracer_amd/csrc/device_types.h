@@ -13,6 +13,7 @@
 namespace rt {
 
 // Internal reference kinds that only live on the traversal stack.
+constexpr uint32_t REF_QNODE = 7u;     // 4-wide node `index` of qnodes / cqnodes (ordered traversal only)
 constexpr uint32_t REF_LISTCONT = 8u;  // resume list `index` at the position stored one entry below
 constexpr uint32_t REF_POPX = 9u;      // leave a transform: restore context `index`
 constexpr uint32_t REF_OTHER = 15u;    // light-list member without pdf_value/random (hittable.rs:51-56 defaults)
@@ -66,7 +67,7 @@ struct alignas(16) WNode {     // 64 B
     uint32_t left, right;      // same references as DNode
     uint32_t meta;             // bit 0: subtree holds a constant medium (keep reference order);
                                // bit 1: right is the same object as left (bvh.rs:41-44)
-    uint32_t _pad;
+    uint32_t qroot;            // root of a BVH without media: 1 + index of its 4-wide root node, else 0
 };
 
 // 4-wide node of the primitive-BVH kernel: two levels of the binary tree collapsed into one
@@ -74,7 +75,7 @@ struct alignas(16) WNode {     // 64 B
 struct alignas(128) QNode {
     float lo[3][4];            // [axis][child] box minimum
     float hi[3][4];            // [axis][child] box maximum
-    uint32_t child[4];         // RT_REF_NODE|q-index, a primitive reference, or RT_REF_NONE (empty slot)
+    uint32_t child[4];         // REF_QNODE|q-index, any other reference (primitive, list, instance), or RT_REF_NONE (empty slot)
     uint32_t _pad[4];
 };
 
@@ -147,7 +148,7 @@ struct DScene {
     uint32_t world;
     int32_t n_lights;          // -1: no light list (material pdf only)
     int32_t lights_is_list;    // 1: HittableList semantics (uniform pick / mean pdf), 0: a single object
-    int32_t _pad;
+    float q_extent;            // largest |coordinate| stored in the 4-wide nodes (margin of the f32 slab test)
 };
 
 } // namespace rt

@@ -96,7 +96,7 @@ uint32_t build_bvh(std::vector<Item>& items, size_t start, size_t end, DNode* no
     n._pad = 0;
     uint32_t medium = 0;
     WNode& wn = wnodes[at];
-    wn._pad = 0;
+    wn.qroot = 0;
     if (span == 1) {
         n.left = n.right = items[start].ref;
         medium = items[start].medium;
@@ -151,6 +151,8 @@ struct Flattener {
     std::map<std::pair<int32_t, int32_t>, uint32_t> memo; // (object, ctx) -> ref
     std::vector<uint8_t> obj_medium;                     // object subtree contains a medium
     std::vector<int32_t> need_node;
+    std::map<uint32_t, int32_t> need_q;                    // BVH root node index -> stack entries its 4-wide copy needs
+    std::vector<uint32_t> bvh_roots;                       // node indices of all BVH roots, in creation order
     std::map<uint32_t, bool> bvh_prim_only;               // BVH root ref -> every leaf is a sphere/quad/triangle
 
     Flattener(const rt_scene_desc* desc, FlatScene& out, std::string& e) : d(desc), f(out), err(e) {}
@@ -454,6 +456,7 @@ struct Flattener {
                     if (k != RT_REF_SPHERE && k != RT_REF_QUAD && k != RT_REF_TRI) { prim_only = false; break; }
                 }
                 bvh_prim_only[ref] = prim_only;
+                bvh_roots.push_back((uint32_t)base);
             }
             break;
         }
@@ -534,7 +537,7 @@ struct Flattener {
         for (int j = 0; j < n; ++j) {
             if (RT_REF_KIND(refs[j]) == RT_REF_NODE) {
                 const uint32_t child = base + (uint32_t)k++;
-                out_refs[j] = make_ref(RT_REF_NODE, child);
+                out_refs[j] = make_ref(REF_QNODE, child);
                 deepest = std::max(deepest, fill_qnode(child, RT_REF_INDEX(refs[j]), depth + 1));
             } else out_refs[j] = refs[j];
         }
@@ -627,6 +630,7 @@ struct Flattener {
             int32_t r;
             if (n.left == n.right && !(n.flags & 1u)) r = l; // the duplicate child is not pushed
             else r = std::max(1 + l, need(n.right));
+            if (f.wnodes[idx].qroot) r = std::max(r, need_q[idx]); // ordered traversal enters the 4-wide copy here
             need_node[idx] = r;
             return r;
         }
@@ -692,25 +696,45 @@ struct Flattener {
         } else {
             f.n_lights = -1;
         }
-        need_node.assign(f.nodes.size(), -1);
+        // 4-wide copies of every BVH that holds no constant medium and has finite bounds (ordered traversal)
+        f.qnodes.reserve(f.nodes.size() / 2 + 16);
+        for (uint32_t root : bvh_roots) {
+            const DNode& n = f.nodes[root];
+            bool ok = !(n.flags & 1u);
+            for (double v : n.bounds) ok = ok && std::isfinite(v);
+            if (!ok) continue;
+            if (f.qnodes.size() & 1u) add_empty_qnode();
+            const uint32_t me = (uint32_t)f.qnodes.size();
+            add_empty_qnode();
+            need_q[root] = fill_qnode(me, root, 0);
+            f.wnodes[root].qroot = me + 1;
+        }
+        for (const QNode& q : f.qnodes)
+            for (int j = 0; j < 4; ++j)
+                if (q.child[j] != RT_REF_NONE)
+                    for (int a = 0; a < 3; ++a) f.q_extent = std::max(f.q_extent, std::max(std::fabs(q.lo[a][j]), std::fabs(q.hi[a][j])));
+        f.q_extent *= 1.0000001f;
         {
             uint32_t r = f.world;
             if (RT_REF_KIND(r) == RT_REF_LIST && f.lists[RT_REF_INDEX(r)].count == 1) r = f.list_items[f.lists[RT_REF_INDEX(r)].first];
             auto it = bvh_prim_only.find(r);
-            if (RT_REF_KIND(r) == RT_REF_NODE && it != bvh_prim_only.end() && it->second) {
-                f.qnodes.reserve(f.nodes.size() / 2 + 16);
-                add_empty_qnode(); // the root
-                f.fast_root = make_ref(RT_REF_NODE, 0u);
-                f.fast_stack = (uint32_t)fill_qnode(0, RT_REF_INDEX(r), 0) + 1;
-                bool finite = true;
-                for (double v : f.world_bounds.b) finite = finite && std::isfinite(v);
-                if (finite) {
-                    f.quant_inflation = quantise_qnodes();
-                    if (f.quant_inflation > 1.25) f.cqnodes.clear();
-                }
+            if (RT_REF_KIND(r) == RT_REF_NODE && it != bvh_prim_only.end() && it->second && f.wnodes[RT_REF_INDEX(r)].qroot) {
+                // the world is one BVH over primitives: the dedicated kernel traverses its 4-wide copy
+                f.fast_root = make_ref(REF_QNODE, f.wnodes[RT_REF_INDEX(r)].qroot - 1);
+                f.fast_stack = (uint32_t)need_q[RT_REF_INDEX(r)] + 1;
+                f.quant_inflation = quantise_qnodes();
+                if (f.quant_inflation > 1.25) f.cqnodes.clear();
             }
         }
+        need_node.assign(f.nodes.size(), -1);
         f.max_stack = (uint32_t)need(f.world) + 1;
+        if (f.max_stack > (uint32_t)STACK_MAX) {
+            // too deep for the general kernel's stack with 4-wide nodes (up to three deferred children per two
+            // binary levels): it keeps the binary nodes; the dedicated kernel has its own spilling stack
+            for (uint32_t root : bvh_roots) f.wnodes[root].qroot = 0;
+            need_node.assign(f.nodes.size(), -1);
+            f.max_stack = (uint32_t)need(f.world) + 1;
+        }
         if (f.max_stack > (uint32_t)STACK_MAX) return fail(RT_E_TOO_LARGE, "scene needs a deeper traversal stack than the kernels carry (32 entries)");
         return RT_OK;
     }

@@ -37,6 +37,7 @@ struct FlatScene {
     uint32_t max_stack = 0;
     uint32_t fast_root = RT_REF_NONE; // set when the world is one BVH whose leaves are all primitives
     uint32_t fast_stack = 0;          // stack entries the primitive-BVH kernel needs
+    float q_extent = 0.0f;            // largest |coordinate| in qnodes
     double quant_inflation = 0.0;     // mean surface-area ratio of the 8-bit child boxes to their f32 boxes
     bool has_medium = false;
     Box world_bounds;

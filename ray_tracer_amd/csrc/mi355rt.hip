@@ -325,7 +325,7 @@ struct rt_scene {
     uint2* fast_spill = nullptr; // HBM overflow of the per-lane stacks: [entry][thread]
     int fast_prim = 0;           // leaf kind of the primitive BVH when uniform, else 0
     bool fast_quant = false;     // the primitive-BVH kernel reads the 64-byte nodes with 8-bit boxes
-    float fast_extent = 0.0f; // largest |coordinate| of the world box (error bound of the f32 slab test)
+    float fast_extent = 0.0f; // largest |coordinate| stored in the 4-wide nodes (error bound of the f32 slab test)
     // render workspace
     PathState ps{};
     uint64_t ws_paths = 0;
@@ -387,9 +387,7 @@ int pick_grid(rt_scene* s) {
     s->grid_blocks = prop.multiProcessorCount * per_cu;
     if (s->flat.fast_root != RT_REF_NONE) {
         s->fast_lds = 0;
-        double ext = 0.0;
-        for (double v : s->flat.world_bounds.b) ext = std::max(ext, std::fabs(v));
-        s->fast_extent = (float)(ext * 1.0000001);
+        s->fast_extent = s->flat.q_extent;
         const bool tr = !s->flat.tris.empty(), sp = !s->flat.spheres.empty(), qd = !s->flat.quads.empty();
         s->fast_prim = (tr && !sp && !qd) ? (int)RT_REF_TRI : ((sp && !tr && !qd) ? (int)RT_REF_SPHERE : 0);
         int fast_per_cu = 0;
@@ -417,7 +415,7 @@ void fill_host_dscene(rt_scene* s) {
     d.lists = f.lists.data(); d.list_items = f.list_items.data(); d.xforms = f.xforms.data();
     d.media = f.media.data(); d.materials = f.materials.data(); d.textures = f.textures.data(); d.images = f.images.data();
     d.image_bytes = f.image_bytes.data(); d.perlins = f.perlins.data(); d.lights = f.lights.data();
-    d.world = f.world; d.n_lights = f.n_lights; d.lights_is_list = f.lights_is_list; d._pad = 0;
+    d.world = f.world; d.n_lights = f.n_lights; d.lights_is_list = f.lights_is_list; d.q_extent = f.q_extent;
 }
 
 int upload_scene(rt_scene* s) {
@@ -426,12 +424,12 @@ int upload_scene(rt_scene* s) {
     int rc;
     if ((rc = upload(s, f.nodes, &d.nodes))) return rc;
     if ((rc = upload(s, f.wnodes, &d.wnodes))) return rc;
-    // only the node format the primitive-BVH kernel will read goes to the device
-    // (MI355RT_QUANT=0 keeps the f32 nodes even when the 8-bit ones were accepted, for A/B measurements)
+    // the f32 4-wide nodes always go to the device (the general kernel's ordered traversal enters them at every BVH
+    // root); the 8-bit copy only when the primitive-BVH kernel will read it
+    // (MI355RT_QUANT=0 keeps that kernel on the f32 nodes even when the 8-bit ones were accepted, for A/B measurements)
     s->fast_quant = !f.cqnodes.empty() && env_int("MI355RT_QUANT", 1) != 0;
-    const std::vector<QNode> no_qnodes;
     const std::vector<CQNode> no_cqnodes;
-    if ((rc = upload(s, s->fast_quant ? no_qnodes : f.qnodes, &d.qnodes))) return rc;
+    if ((rc = upload(s, f.qnodes, &d.qnodes))) return rc;
     if ((rc = upload(s, s->fast_quant ? f.cqnodes : no_cqnodes, &d.cqnodes))) return rc;
     if ((rc = upload(s, f.spheres, &d.spheres))) return rc;
     if ((rc = upload(s, f.quads, &d.quads))) return rc;
@@ -446,7 +444,7 @@ int upload_scene(rt_scene* s) {
     if ((rc = upload(s, f.image_bytes, &d.image_bytes))) return rc;
     if ((rc = upload(s, f.perlins, &d.perlins))) return rc;
     if ((rc = upload(s, f.lights, &d.lights))) return rc;
-    d.world = f.world; d.n_lights = f.n_lights; d.lights_is_list = f.lights_is_list; d._pad = 0;
+    d.world = f.world; d.n_lights = f.n_lights; d.lights_is_list = f.lights_is_list; d.q_extent = f.q_extent;
     void* c = nullptr;
     HIP_TRY(hipMalloc(&c, C_WORDS * sizeof(unsigned long long)));
     s->allocs.push_back(c);
@@ -702,7 +700,8 @@ int rt_scene_get_wide_nodes(const rt_scene* s, uint64_t first, uint64_t count, r
         o.has_box8 = has8 ? 1 : 0;
         o._pad = 0;
         for (int j = 0; j < 4; ++j) {
-            o.child[j] = q.child[j];
+            // inner children are reported as RT_REF_NODE | wide index (the internal kind stays internal)
+            o.child[j] = RT_REF_KIND(q.child[j]) == REF_QNODE ? ((RT_REF_NODE << 28) | RT_REF_INDEX(q.child[j])) : q.child[j];
             for (int a = 0; a < 3; ++a) {
                 o.box32[j][2 * a] = q.lo[a][j];
                 o.box32[j][2 * a + 1] = q.hi[a][j];

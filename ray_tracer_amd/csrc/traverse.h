@@ -84,6 +84,13 @@ RT_DEV void load_wnode(const WNode* wnodes, uint32_t idx, WNodeLoad& n) {
     n.left = d.x; n.right = d.y; n.meta = d.z; n.pad = d.w;
 }
 
+RT_DEV void sort2(float& ka, uint32_t& ra, float& kb, uint32_t& rb) { // ascending by key
+    const bool sw = kb < ka;
+    const float k0 = sw ? kb : ka, k1 = sw ? ka : kb;
+    const uint32_t r0 = sw ? rb : ra, r1 = sw ? ra : rb;
+    ka = k0; kb = k1; ra = r0; rb = r1;
+}
+
 // One primitive against the lane's ray over (tmin, best.t]; a closer hit replaces `best`.
 RT_DEV void test_primitive(const DScene& S, uint32_t ref, const RayD& ray, int32_t ctx, double time, double tmin, Best& best) {
     const uint32_t kind = ref >> 28, idx = ref & 0x0FFFFFFFu;
@@ -125,7 +132,11 @@ __device__ __forceinline__ void traverse(const DScene& S, uint32_t root, RayD ra
         if (ORDERED && kind == RT_REF_NODE) {
             WNodeLoad wn;
             load_wnode(S.wnodes, idx, wn);
-            if (!(wn.meta & 1u)) {
+            if (wn.pad) { // root of a BVH without media: continue in its 4-wide copy
+                wide_done = true;
+                cur = make_ref(REF_QNODE, wn.pad - 1u);
+                pop = false;
+            } else if (!(wn.meta & 1u)) {
                 wide_done = true;
                 double nl = 0.0, nr = 0.0;
                 const bool hl = slab_test_wide(wn.lb, ray, tmin, best.t, nl);
@@ -141,6 +152,46 @@ __device__ __forceinline__ void traverse(const DScene& S, uint32_t root, RayD ra
             }
         }
         if (wide_done) {
+        } else if (ORDERED && kind == REF_QNODE) {
+            // 4-wide node: conservative f32 slab test of the four child boxes, nearest child first.  The
+            // children may be anything (primitives, lists, instances, further nodes).
+            const float4* row = reinterpret_cast<const float4*>(S.qnodes + idx);
+            const float4 lox = row[0], loy = row[1], loz = row[2];
+            const float4 hix = row[3], hiy = row[4], hiz = row[5];
+            const float4 chf = row[6];
+            Ray32 q;
+            make_ray32(ray, S.q_extent, q);
+            const float tmin32 = f32_round_down(tmin), best32 = f32_round_up(best.t);
+            const float lx[4] = {lox.x, lox.y, lox.z, lox.w}, hx[4] = {hix.x, hix.y, hix.z, hix.w};
+            const float ly[4] = {loy.x, loy.y, loy.z, loy.w}, hy[4] = {hiy.x, hiy.y, hiy.z, hiy.w};
+            const float lz[4] = {loz.x, loz.y, loz.z, loz.w}, hz[4] = {hiz.x, hiz.y, hiz.z, hiz.w};
+            uint32_t rf[4] = {__float_as_uint(chf.x), __float_as_uint(chf.y), __float_as_uint(chf.z), __float_as_uint(chf.w)};
+            float key[4];
+            int nh = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float nx = q.neg[0] ? hx[j] : lx[j], fx = q.neg[0] ? lx[j] : hx[j];
+                const float ny = q.neg[1] ? hy[j] : ly[j], fy = q.neg[1] ? ly[j] : hy[j];
+                const float nz = q.neg[2] ? hz[j] : lz[j], fz = q.neg[2] ? lz[j] : hz[j];
+                const float tn = fmaxf(fmaxf(__builtin_fmaf(nx, q.inv[0], q.cn[0]), __builtin_fmaf(ny, q.inv[1], q.cn[1])), fmaxf(__builtin_fmaf(nz, q.inv[2], q.cn[2]), tmin32));
+                const float tf = fminf(fminf(__builtin_fmaf(fx, q.inv[0], q.cf[0]), __builtin_fmaf(fy, q.inv[1], q.cf[1])), fminf(__builtin_fmaf(fz, q.inv[2], q.cf[2]), best32));
+                const bool hit = (tn <= tf) && (rf[j] != RT_REF_NONE);
+                key[j] = hit ? tn : __builtin_inff();
+                nh += hit ? 1 : 0;
+                if (COUNT) n_nodes += rf[j] != RT_REF_NONE ? 1u : 0u;
+            }
+            if (nh > 0) {
+                sort2(key[0], rf[0], key[1], rf[1]);
+                sort2(key[2], rf[2], key[3], rf[3]);
+                sort2(key[0], rf[0], key[2], rf[2]);
+                sort2(key[1], rf[1], key[3], rf[3]);
+                sort2(key[1], rf[1], key[2], rf[2]);
+                if (nh > 3) { stk[sp * BLOCK] = rf[3]; ++sp; }
+                if (nh > 2) { stk[sp * BLOCK] = rf[2]; ++sp; }
+                if (nh > 1) { stk[sp * BLOCK] = rf[1]; ++sp; }
+                cur = rf[0];
+                pop = false;
+            }
         } else if (kind == RT_REF_NODE) {
             NodeLoad n;
             load_node(S.nodes, idx, n);
