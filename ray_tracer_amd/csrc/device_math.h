@@ -265,6 +265,24 @@ RT_DEV bool quad_test(const DQuad& qd, const RayD& r, double tmin, double tmax, 
     return true;
 }
 
+// The same test without early exits: `t` of the plane hit and whether the point lies inside the quad, the
+// interval check left to the caller.  Every condition of quad_test is a pure predicate of the inputs, so
+// (geometric conditions) && (tmin <= t <= tmax) is the same boolean; written branch-free so that two
+// evaluations placed next to each other overlap their f64 dependency chains.
+RT_DEV bool quad_eval(const DQuad& qd, const RayD& r, double& t_out) {
+    D3 n = d3(qd.n[0], qd.n[1], qd.n[2]);
+    D3 o = d3(r.ox, r.oy, r.oz), d = d3(r.dx, r.dy, r.dz);
+    double denom = dot(n, d);
+    double t = (qd.d - dot(n, o)) / denom;
+    D3 intersection = o + t * d;
+    D3 hp = intersection - d3(qd.q[0], qd.q[1], qd.q[2]);
+    D3 w = d3(qd.w[0], qd.w[1], qd.w[2]);
+    double alpha = dot(w, cross(hp, d3(qd.v[0], qd.v[1], qd.v[2])));
+    double beta = dot(w, cross(d3(qd.u[0], qd.u[1], qd.u[2]), hp));
+    t_out = t;
+    return !(fabs(denom) < 1e-8) & (0.0 <= alpha) & (alpha <= 1.0) & (0.0 <= beta) & (beta <= 1.0);
+}
+
 // Triangle::hit (triangle.rs:153-188): Moeller-Trumbore with edges recomputed per call.
 RT_DEV bool tri_test(D3 v0, D3 v1, D3 v2, const RayD& r, double tmin, double tmax, double& t_out, double& u_out, double& v_out) {
     D3 o = d3(r.ox, r.oy, r.oz), d = d3(r.dx, r.dy, r.dz);

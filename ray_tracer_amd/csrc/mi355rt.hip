@@ -82,6 +82,16 @@ __device__ __forceinline__ unsigned long long wave_fetch(unsigned long long* cou
     return ((unsigned long long)hi << 32) | lo;
 }
 
+// Rays a wave takes from the global counter per atomic: all waves increment the same word, and the chip
+// serves same-address atomics at roughly 10 ns each, so one atomic per 64 rays alone would cap a kernel
+// near 6 G rays/s.  Up to 16 wave-loads per fetch, fewer when the batch is small, so that every wave
+// still gets several fetches.
+__device__ __forceinline__ unsigned long long wave_chunk(unsigned long long n) {
+    const unsigned long long waves = (unsigned long long)gridDim.x * (blockDim.x / 64u);
+    const unsigned long long k = n / (waves * 8ull * 64ull);
+    return 64ull * (k < 1ull ? 1ull : (k > 16ull ? 16ull : k));
+}
+
 template <bool COUNT, bool ORDERED>
 __global__ __launch_bounds__(BLOCK) void closest_hit_kernel(DScene S, rt_ray_batch rays, unsigned long long n, rt_hit_batch hits,
                                                             unsigned long long seed, unsigned long long* counters) {
@@ -89,10 +99,12 @@ __global__ __launch_bounds__(BLOCK) void closest_hit_kernel(DScene S, rt_ray_bat
     uint32_t* stk = s_stack + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t nn = 0, np = 0;
+    const unsigned long long chunk = wave_chunk(n);
     for (;;) {
-        unsigned long long base = wave_fetch(&counters[C_WORK], 64ull);
+        const unsigned long long base = wave_fetch(&counters[C_WORK], chunk);
         if (base >= n) break;
-        unsigned long long i = base + lane;
+        for (unsigned long long off = 0; off < chunk; off += 64ull) {
+        unsigned long long i = base + off + lane;
         if (i < n) {
             WorldRay w{rays.ox, rays.oy, rays.oz, rays.dx, rays.dy, rays.dz, i};
             RayD r;
@@ -133,6 +145,7 @@ __global__ __launch_bounds__(BLOCK) void closest_hit_kernel(DScene S, rt_ray_bat
                 if (hits.py) hits.py[i] = 0.0;
                 if (hits.pz) hits.pz[i] = 0.0;
             }
+        }
         }
     }
     if (COUNT) {
@@ -201,10 +214,12 @@ __global__ __launch_bounds__(BLOCK) void extend_kernel(DScene S, PathState ps, i
     const unsigned long long n = ps.counters[C_LIVE_IN];
     const uint32_t* queue = ps.queue[qsel];
     uint32_t nn = 0, np = 0;
+    const unsigned long long chunk = wave_chunk(n);
     for (;;) {
-        unsigned long long base = wave_fetch(&ps.counters[C_WORK], 64ull);
+        const unsigned long long base = wave_fetch(&ps.counters[C_WORK], chunk);
         if (base >= n) break;
-        unsigned long long q = base + lane;
+        for (unsigned long long off = 0; off < chunk; off += 64ull) {
+        unsigned long long q = base + off + lane;
         if (q < n) {
             uint32_t p = queue[q];
             PathRec* rec = ps.rec + p;
@@ -224,67 +239,77 @@ __global__ __launch_bounds__(BLOCK) void extend_kernel(DScene S, PathState ps, i
             rec->hit_ctx = b.ctx;
             rec->rng_index = g.index;
         }
+        }
     }
 }
 
-#ifndef SHADE_WAVES
-#define SHADE_WAVES 1
-#endif
-__global__ __launch_bounds__(BLOCK, SHADE_WAVES) void shade_kernel(DScene S, CamD cam, PathState ps, int qsel, unsigned long long seed, BatchGeom bg, int last_bounce) {
+constexpr int SHADE_ROUNDS = 16; // wave-loads of paths whose survivors share one queue reservation
+__global__ __launch_bounds__(BLOCK) void shade_kernel(DScene S, CamD cam, PathState ps, int qsel, unsigned long long seed, BatchGeom bg, int last_bounce) {
     const unsigned long long n = ps.counters[C_LIVE_IN];
     const uint32_t* qin = ps.queue[qsel];
     uint32_t* qout = ps.queue[qsel ^ 1];
+    // Survivors of up to SHADE_ROUNDS wave-loads are collected in LDS and get their place in the next queue
+    // with ONE atomic (all waves bump the same counter; one atomic per 64 paths capped this kernel).
+    __shared__ uint32_t s_keep[(BLOCK / 64) * SHADE_ROUNDS * 64];
+    uint32_t* keep = s_keep + (threadIdx.x >> 6) * (SHADE_ROUNDS * 64);
     const uint32_t lane = threadIdx.x & 63u;
-    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
-    // every lane of a wave runs the same number of iterations so the ballot below stays convergent
-    const unsigned long long rounds = (n + stride - 1) / stride;
-    unsigned long long q = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    for (unsigned long long it = 0; it < rounds; ++it, q += stride) {
-        bool alive = false;
-        uint32_t p = 0;
-        if (q < n) {
-            p = qin[q];
-            PathRec* rec = ps.rec + p;
-            D3 beta = d3p(rec->beta);
-            D3 L = d3p(rec->L);
-            Best b;
-            b.t = rec->hit_t; b.ref = rec->hit_ref; b.ctx = rec->hit_ctx;
-            if (b.ref == RT_REF_NONE) { // camera.rs:258-260
-                L = L + beta * d3p(cam.background);
-            } else {
-                const WorldRay w = path_ray(ps, p);
-                double time = rec->time;
-                HitRec h;
-                finalize(S, w, time, b, h);
-                uint32_t s_local = p / bg.npix, pix = p - s_local * bg.npix;
-                int32_t i = bg.x0 + (int32_t)(pix % (uint32_t)bg.tw);
-                int32_t j = bg.y0 + (int32_t)(pix / (uint32_t)bg.tw);
-                Rng g{seed, 0u, (uint32_t)(j * cam.image_width + i), (uint32_t)(bg.sample0 + (int32_t)s_local), rec->rng_index};
-                D3 ray_dir = d3p(rec->d);
-                D3 no, nd;
-                alive = shade_hit(S, h, ray_dir, g, beta, L, no, nd);
-                if (alive) {
-                    if (last_bounce) { // the next ray_color call has depth 0 and returns black (camera.rs:252-254)
-                        L = L + beta * d3(0.0, 0.0, 0.0);
-                        alive = false;
-                    } else {
-                        rec->o[0] = no.x; rec->o[1] = no.y; rec->o[2] = no.z;
-                        rec->d[0] = nd.x; rec->d[1] = nd.y; rec->d[2] = nd.z;
-                        rec->beta[0] = beta.x; rec->beta[1] = beta.y; rec->beta[2] = beta.z;
-                        rec->rng_index = g.index;
+    const unsigned long long waves = (unsigned long long)gridDim.x * (blockDim.x / 64u);
+    const unsigned long long wave_id = (unsigned long long)blockIdx.x * (blockDim.x / 64u) + (threadIdx.x >> 6);
+    unsigned long long rounds = n / (waves * 8ull * 64ull); // wave-loads per chunk: several chunks per wave, at most SHADE_ROUNDS
+    rounds = rounds < 1ull ? 1ull : (rounds > (unsigned long long)SHADE_ROUNDS ? (unsigned long long)SHADE_ROUNDS : rounds);
+    const unsigned long long chunk = rounds * 64ull;
+    for (unsigned long long base = wave_id * chunk; base < n; base += waves * chunk) {
+        uint32_t kept = 0; // wave-uniform
+        for (unsigned long long off = 0; off < chunk; off += 64ull) {
+            const unsigned long long q = base + off + lane;
+            bool alive = false;
+            uint32_t p = 0;
+            if (q < n) {
+                p = qin[q];
+                PathRec* rec = ps.rec + p;
+                D3 beta = d3p(rec->beta);
+                D3 L = d3p(rec->L);
+                Best b;
+                b.t = rec->hit_t; b.ref = rec->hit_ref; b.ctx = rec->hit_ctx;
+                if (b.ref == RT_REF_NONE) { // camera.rs:258-260
+                    L = L + beta * d3p(cam.background);
+                } else {
+                    const WorldRay w = path_ray(ps, p);
+                    double time = rec->time;
+                    HitRec h;
+                    finalize(S, w, time, b, h);
+                    uint32_t s_local = p / bg.npix, pix = p - s_local * bg.npix;
+                    int32_t i = bg.x0 + (int32_t)(pix % (uint32_t)bg.tw);
+                    int32_t j = bg.y0 + (int32_t)(pix / (uint32_t)bg.tw);
+                    Rng g{seed, 0u, (uint32_t)(j * cam.image_width + i), (uint32_t)(bg.sample0 + (int32_t)s_local), rec->rng_index};
+                    D3 ray_dir = d3p(rec->d);
+                    D3 no, nd;
+                    alive = shade_hit(S, h, ray_dir, g, beta, L, no, nd);
+                    if (alive) {
+                        if (last_bounce) { // the next ray_color call has depth 0 and returns black (camera.rs:252-254)
+                            L = L + beta * d3(0.0, 0.0, 0.0);
+                            alive = false;
+                        } else {
+                            rec->o[0] = no.x; rec->o[1] = no.y; rec->o[2] = no.z;
+                            rec->d[0] = nd.x; rec->d[1] = nd.y; rec->d[2] = nd.z;
+                            rec->beta[0] = beta.x; rec->beta[1] = beta.y; rec->beta[2] = beta.z;
+                            rec->rng_index = g.index;
+                        }
                     }
                 }
+                rec->L[0] = L.x; rec->L[1] = L.y; rec->L[2] = L.z;
             }
-            rec->L[0] = L.x; rec->L[1] = L.y; rec->L[2] = L.z;
+            const unsigned long long mask = __ballot(alive);
+            if (alive) keep[kept + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = p;
+            kept += (uint32_t)__popcll(mask);
         }
-        // compact: surviving paths of this wave take consecutive slots of the next queue
-        unsigned long long mask = __ballot(alive);
-        if (mask) {
-            int leader = __ffsll((long long)mask) - 1;
-            unsigned long long base = 0;
-            if ((int)lane == leader) base = atomicAdd(&ps.counters[C_LIVE_OUT], (unsigned long long)__popcll(mask));
-            uint32_t base_lo = (uint32_t)__shfl((int)(uint32_t)base, leader);
-            if (alive) qout[base_lo + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = p;
+        if (kept) { // surviving paths of this chunk take consecutive slots of the next queue
+            unsigned long long slot = 0;
+            if (lane == 0u) slot = atomicAdd(&ps.counters[C_LIVE_OUT], (unsigned long long)kept);
+            const uint32_t slot_lo = __builtin_amdgcn_readfirstlane((uint32_t)slot);
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t k = lane; k < kept; k += 64u) qout[slot_lo + k] = keep[k];
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }
@@ -321,6 +346,7 @@ struct rt_scene {
     rt_counters counters{};
     int grid_blocks = 0;
     int fast_grid_blocks = 0;
+    int extend_blocks = 0, shade_blocks = 0;
     size_t fast_lds = 0;
     uint2* fast_spill = nullptr; // HBM overflow of the per-lane stacks: [entry][thread]
     int fast_prim = 0;           // leaf kind of the primitive BVH when uniform, else 0
@@ -383,8 +409,11 @@ int pick_grid(rt_scene* s) {
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, closest_hit_kernel<false, true>, BLOCK, 0));
     int per_cu2 = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, extend_kernel, BLOCK, 0));
-    per_cu = std::max(1, std::min(per_cu, per_cu2));
-    s->grid_blocks = prop.multiProcessorCount * per_cu;
+    int per_cu3 = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu3, shade_kernel, BLOCK, 0));
+    s->grid_blocks = prop.multiProcessorCount * std::max(1, per_cu);      // batched closest hit (general kernel)
+    s->extend_blocks = prop.multiProcessorCount * std::max(1, per_cu2);   // each kernel fills the chip at its own occupancy
+    s->shade_blocks = prop.multiProcessorCount * std::max(1, per_cu3);
     if (s->flat.fast_root != RT_REF_NONE) {
         s->fast_lds = 0;
         s->fast_extent = s->flat.q_extent;
@@ -574,7 +603,9 @@ int render_impl(rt_scene* s, const rt_camera* cam, uint64_t seed, const rt_work*
             const bool fast_extend = s->flat.fast_root != RT_REF_NONE && env_int("MI355RT_FAST_EXTEND", 1) != 0;
             for (int32_t bounce = 0; bounce < cam->max_depth && live > 0; ++bounce) {
                 uint64_t waves = (live + 63) / 64;
-                int blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)s->grid_blocks, (waves + (BLOCK / 64) - 1) / (BLOCK / 64)));
+                const uint64_t want = (waves + (BLOCK / 64) - 1) / (BLOCK / 64);
+                const int blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)s->extend_blocks, want));
+                const int sblocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)s->shade_blocks, want));
                 if (fast_extend) {
                     // the world is one BVH over primitives: the primitive-BVH kernel reads the rays straight out of
                     // the path records (strided views) and writes hit_t / hit_ref back into them; no transforms and
@@ -592,7 +623,7 @@ int render_impl(rt_scene* s, const rt_camera* cam, uint64_t seed, const rt_work*
                 } else {
                     hipLaunchKernelGGL(extend_kernel, dim3(blocks), dim3(BLOCK), 0, st, s->dev, ps, qsel, (unsigned long long)seed, bg, cam->image_width);
                 }
-                hipLaunchKernelGGL(shade_kernel, dim3(blocks), dim3(BLOCK), 0, st, s->dev, cd, ps, qsel, (unsigned long long)seed, bg, bounce == cam->max_depth - 1 ? 1 : 0);
+                hipLaunchKernelGGL(shade_kernel, dim3(sblocks), dim3(BLOCK), 0, st, s->dev, cd, ps, qsel, (unsigned long long)seed, bg, bounce == cam->max_depth - 1 ? 1 : 0);
                 hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, st, s->d_counters);
                 s->counters.extend_launches += 1;
                 qsel ^= 1;

@@ -217,6 +217,21 @@ __device__ __forceinline__ void traverse(const DScene& S, uint32_t root, RayD ra
             while (pos < l.count) {
                 const uint32_t item = S.list_items[l.first + pos];
                 const uint32_t ik = item >> 28;
+                if (ik == RT_REF_QUAD && pos + 1 < l.count) {
+                    // two quads in a row (the walls of a room, the sides of a box): both are evaluated before
+                    // either is accepted, so their f64 chains overlap; acceptance stays in list order
+                    const uint32_t item2 = S.list_items[l.first + pos + 1];
+                    if ((item2 >> 28) == RT_REF_QUAD) {
+                        if (COUNT) n_prims += 2;
+                        double ta, tb;
+                        const bool ia = quad_eval(S.quads[item & 0x0FFFFFFFu], ray, ta);
+                        const bool ib = quad_eval(S.quads[item2 & 0x0FFFFFFFu], ray, tb);
+                        if (ia && tmin <= ta && ta <= best.t) { best.t = ta; best.ref = item; best.ctx = ctx; }
+                        if (ib && tmin <= tb && tb <= best.t) { best.t = tb; best.ref = item2; best.ctx = ctx; }
+                        pos += 2;
+                        continue;
+                    }
+                }
                 if (ik == RT_REF_TRI || ik == RT_REF_SPHERE || ik == RT_REF_QUAD) {
                     if (COUNT) ++n_prims;
                     test_primitive(S, item, ray, ctx, time, tmin, best);
