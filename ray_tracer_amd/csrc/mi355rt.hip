@@ -627,9 +627,10 @@ int render_impl(rt_scene* s, const rt_camera* cam, uint64_t seed, const rt_work*
                 hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, st, s->d_counters);
                 s->counters.extend_launches += 1;
                 qsel ^= 1;
-                // `live` only sizes the next launches (the kernels read the exact count on the device);
-                // refresh it from the device every few bounces so dead batches stop early.
-                if ((bounce & 3) == 3 || bounce < 4) {
+                // `live` only sizes the next launches and ends a dead batch early (the kernels read the exact count
+                // on the device).  Each refresh is a host round trip with the GPU idle, which costs more than a few
+                // over-sized launches, so it happens at bounces 2, 5, 9, then every 8th.
+                if (bounce == 2 || bounce == 5 || bounce == 9 || (bounce > 9 && (bounce & 7) == 1)) {
                     HIP_TRY(hipMemcpyAsync(s->h_counters, s->d_counters, C_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
                     HIP_TRY(hipStreamSynchronize(st));
                     live = s->h_counters[C_LIVE_IN];
