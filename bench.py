@@ -38,6 +38,7 @@ def main() -> None:
     ap.add_argument("--cpu-sample", type=int, default=1 << 23, help="rays of the batch timed on the host cores")
     ap.add_argument("--count-sample", type=int, default=1 << 16, help="rays used for the reference-order visit counts")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-render", action="store_true", help="skip the camera-samples/s figure (second half of the metric)")
     args = ap.parse_args()
 
     import numpy as np
@@ -171,10 +172,43 @@ def main() -> None:
             tie = np.isclose(t_gpu, ref["t"], rtol=1e-6, atol=0) | (np.isinf(t_gpu) & np.isinf(ref["t"]))
             out["config"]["parity_vs_oracle"] = {"rays": int(mc), "prim_mismatch_not_tie": int((~same & ~tie).sum()),
                                                  "prim_mismatch_tie": int((~same & tie).sum())}
+    if rank == 0 and world_size == 1 and not args.no_render:
+        out["render"] = _render_figure(rt, F, scenes, np, with_cpu=not args.no_cpu)
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def _render_figure(rt, F, scenes, np, with_cpu):
+    """Second half of the metric: camera samples/s of a full frame (the scene live at the reference's HEAD,
+    Cornell box with mixture-PDF light sampling, 600x600, depth 50) next to the oracle on a few rows of it."""
+    world, lights, cam = scenes.cornell_box(image_width=600, samples_per_pixel=100, max_depth=50)
+    desc = rt.SceneDesc.from_world(world, lights)
+    gpu = rt.Scene(desc)
+    c, d = cam.to_struct(), cam.derived()
+    n_strata = d.sqrt_spp * d.sqrt_spp
+    paths = cam.image_width * d.image_height * n_strata
+    gpu.render(c, seed=1, work=F.rt_work(0, 0, cam.image_width, 8, 0, 1))  # workspace + code
+    t0 = time.perf_counter()
+    accum = gpu.render(c, seed=1)
+    wall = time.perf_counter() - t0
+    fig = {"metric": "camera samples/s", "scene": f"cornell_box {cam.image_width}x{d.image_height}, {n_strata} samples/pixel, depth {cam.max_depth}",
+           "value": paths / wall, "unit": "samples/s", "ms_frame": 1e3 * wall, "device_ms": gpu.counters().ms_last_render}
+    if with_cpu:
+        import oracle_ffi as O
+        rows, threads = 120, min(16, os.cpu_count() or 1)
+        y0 = d.image_height // 2
+        acc = np.zeros_like(accum)
+        t0 = time.perf_counter()
+        O.OracleScene(desc).render(c, seed=1, work=F.rt_work(0, y0, cam.image_width, y0 + rows, 0, n_strata), accum=acc, nthreads=threads)
+        cpu_s = time.perf_counter() - t0
+        sa = np.nan_to_num(accum[y0:y0 + rows] * d.pixel_samples_scale, posinf=1e6)
+        sb = np.nan_to_num(acc[y0:y0 + rows] * d.pixel_samples_scale, posinf=1e6)
+        fig["cpu_baseline"] = {"value": cam.image_width * rows * n_strata / cpu_s, "unit": "samples/s", "cores": threads, "kind": "port",
+                               "sample": f"{rows} image rows of the same frame, all strata, {cpu_s:.1f} s"}
+        fig["rmse_vs_oracle_rows"] = float(np.sqrt(np.mean((sa - sb) ** 2)))
+    return fig
 
 
 def _traffic_from_env():
