@@ -210,3 +210,55 @@ def test_degenerate_batches():
     o = np.array([[-2, 0, 0], [-2, 0, 0], [3, 5, 0], [3, 0.4, 0], [1, 1, 1]], float)
     d = np.array([[1, 0, 0], [0, 0, 0], [0, -1, 0], [1, 0, 0], [0, 0, 0]], float)
     compare(desc, o, d, min_hits=2)
+
+
+def _edge_rays(bounds, n_grid=12):
+    """Axis-parallel rays (zero direction components: the slab test sees 0 * inf), rays starting exactly on
+    box planes of a regular grid, diagonal rays through corners, and a zero direction."""
+    lo = np.array([bounds[0], bounds[2], bounds[4]])
+    hi = np.array([bounds[1], bounds[3], bounds[5]])
+    g = np.linspace(0.0, 1.0, n_grid)
+    o, d = [], []
+    for ax in range(3):
+        for sgn in (1.0, -1.0):
+            for a in g:
+                for b in g:
+                    p = np.array([a, b, a])
+                    p[ax] = -0.25 if sgn > 0 else 1.25
+                    p[(ax + 1) % 3] = a
+                    p[(ax + 2) % 3] = b
+                    o.append(lo + p * (hi - lo))
+                    e = np.zeros(3)
+                    e[ax] = sgn
+                    d.append(e)
+    for a in g:  # diagonals and rays in a coordinate plane
+        o.append(lo + np.array([a, 0.0, 0.0]) * (hi - lo)); d.append(np.array([0.0, 1.0, 1.0]))
+        o.append(lo + np.array([1.0, a, 1.0]) * (hi - lo)); d.append(np.array([-1.0, 0.0, -1.0]))
+        o.append(lo - 0.1 * (hi - lo)); d.append((hi - lo) * np.array([1.0, a + 0.01, 1.0]))
+    o.append(0.5 * (lo + hi)); d.append(np.zeros(3))
+    return np.array(o), np.array(d)
+
+
+def test_primitive_bvh_kernel_edge_cases():
+    """The dedicated kernel for BVH-only worlds, both node formats: ragged batch sizes around its per-wave
+    work ranges, axis-parallel and plane-grazing rays, caller-supplied intervals with negative tmin."""
+    m = rt.Lambertian(rt.Color(.5, .5, .5))
+    soup = rt.SceneDesc.from_world(rt.Mesh(scenes.triangle_soup(3000, seed=31, edge=0.08), m))  # 8-bit nodes accepted
+    lst = rt.HittableList()
+    lst.add(rt.Sphere(rt.Point3(0.5, -100.0, 0.5), 100.0, m))  # dwarfs the rest: f32 nodes are kept
+    rng = np.random.default_rng(5)
+    for c in rng.uniform(0.0, 1.0, (300, 3)):
+        lst.add(rt.Sphere(rt.Point3(*c), 0.03, m))
+    spheres = rt.SceneDesc.from_world(rt.BvhNode(lst))
+    assert rt.Scene(soup, host_only=True).wide_nodes()[0]["has_box8"] == 1
+    assert rt.Scene(spheres, host_only=True).wide_nodes()[0]["has_box8"] == 0
+    for desc, min_hits in ((soup, 300), (spheres, 300)):
+        o, d = _edge_rays([0, 1, 0, 1, 0, 1])
+        compare(desc, o, d, min_hits=min_hits, flags=F.RT_HIT_ORDERED)
+        oo, dd, tm = scenes.incoherent_rays(5000, [0, 1, 0, 1, 0, 1], seed=32)
+        g = np.random.default_rng(6)
+        tmin = g.uniform(-0.5, 0.05, len(oo))   # mostly negative: hits behind the origin count
+        tmax = g.uniform(0.05, 0.6, len(oo))
+        compare(desc, oo, dd, time=tm, tmin=tmin, tmax=tmax, min_hits=500, flags=F.RT_HIT_ORDERED)
+        for n in (1, 2, 63, 64, 65, 129, 1000):
+            compare(desc, oo[:n], dd[:n], min_hits=0, flags=F.RT_HIT_ORDERED)
