@@ -125,7 +125,7 @@ def main() -> None:
                    "scene_build_s": build_s},
     }
 
-    if rank == 0 and world_size == 1:
+    if rank == 0:
         import oracle_ffi as O  # the CPU oracle: checker and reported baseline only
         cpu = O.OracleScene(desc)
         # reference-order visit counts per ray (define the algorithmic bytes of a launch)
@@ -151,7 +151,7 @@ def main() -> None:
             # measured L2 <-> fabric bytes per launch (profiles/) over this run's kernel time: the binding roof
             out["roofline"]["traffic_gbs"] = out["roofline"]["traffic"] / (avg_ms * 1e-3) / 1e9
             out["roofline"]["traffic_frac"] = out["roofline"]["traffic_gbs"] / HBM_PEAK_GBS
-        if not args.no_cpu:
+        if not args.no_cpu and world_size == 1:
             threads = min(16, os.cpu_count() or 1)
             mc = min(args.cpu_sample, n)
             t1 = time.perf_counter()

@@ -98,12 +98,40 @@ RT_DEV D3 random_in_unit_disk(Rng& g) { // camera.rs:238
         if (length_squared(p) < 1.0) return p;
     }
 }
+// sin and cos of phi = 2*pi*r for r in [0, 1): the angle of every azimuth sample (pdf.rs:58, sphere.rs:57-67).
+// The quadrant is split off in r (exact), the remainder times 2*pi lies in [-pi/4, pi/4] and goes through
+// the fdlibm kernel polynomials (< 1 ulp).  The general library routines carry a large-argument reduction
+// the samplers never need, and cost several times the instructions and registers.  The result may differ
+// from a correctly rounded sin(fl(2*pi*r)) in the last place, as any two libm implementations do.
+RT_DEV void sincos_2pi(double r, double& sn, double& cs) {
+    const double q = rint(4.0 * r);             // 0..4
+    const double f = r - 0.25 * q;              // exact, |f| <= 1/8
+    const double x = __builtin_fma(f, 2.449293598294706414e-16, f * 6.283185307179586477); // 2*pi = hi + lo
+    const double z = x * x;
+    // __kernel_sin / __kernel_cos (fdlibm k_sin.c, k_cos.c)
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double ps = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+    const double ks = x + (z * x) * (S1 + z * ps);
+    const double pc = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+    const double hz = 0.5 * z;
+    const double w = 1.0 - hz;
+    const double kc = w + (((1.0 - w) - hz) + z * pc);
+    const int qi = (int)q & 3;
+    const double s0 = (qi & 1) ? kc : ks, c0 = (qi & 1) ? ks : kc;
+    sn = (qi & 2) ? -s0 : s0;
+    cs = ((qi + 1) & 2) ? -c0 : c0;
+}
+
 RT_DEV D3 random_cosine_direction(Rng& g) { // pdf.rs:58
     double r1 = g.next();
     double r2 = g.next();
-    double phi = 2.0 * D_PI * r1;
-    double x = cos(phi) * sqrt(r2);
-    double y = sin(phi) * sqrt(r2);
+    double sphi, cphi;
+    sincos_2pi(r1, sphi, cphi);
+    double x = cphi * sqrt(r2);
+    double y = sphi * sqrt(r2);
     double z = sqrt(1.0 - r2);
     return d3(x, y, z);
 }

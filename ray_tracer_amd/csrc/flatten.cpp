@@ -176,6 +176,7 @@ struct Flattener {
                 o.scale = 1.0 / t.scale; // inv_scale (texture.rs:43)
                 break;
             case RT_TEX_IMAGE:
+                f.uses_uv = true;
                 if (t.image >= 0) {
                     if ((uint64_t)t.image >= d->n_images) return fail(RT_E_INVALID, "image texture: image out of range");
                     const rt_image& im = d->images[t.image];

@@ -40,6 +40,7 @@ struct FlatScene {
     float q_extent = 0.0f;            // largest |coordinate| in qnodes
     double quant_inflation = 0.0;     // mean surface-area ratio of the 8-bit child boxes to their f32 boxes
     bool has_medium = false;
+    bool uses_uv = false;             // an image texture exists: shading needs the spheres' (u,v)
     Box world_bounds;
 };
 

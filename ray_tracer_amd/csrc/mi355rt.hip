@@ -277,7 +277,7 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(DScene S, CamD cam, PathSt
                     const WorldRay w = path_ray(ps, p);
                     double time = rec->time;
                     HitRec h;
-                    finalize(S, w, time, b, h);
+                    finalize(S, w, time, b, h, S.uses_uv != 0u); // only an image texture reads u,v (texture.rs:88-107)
                     uint32_t s_local = p / bg.npix, pix = p - s_local * bg.npix;
                     int32_t i = bg.x0 + (int32_t)(pix % (uint32_t)bg.tw);
                     int32_t j = bg.y0 + (int32_t)(pix / (uint32_t)bg.tw);
@@ -444,7 +444,7 @@ void fill_host_dscene(rt_scene* s) {
     d.lists = f.lists.data(); d.list_items = f.list_items.data(); d.xforms = f.xforms.data();
     d.media = f.media.data(); d.materials = f.materials.data(); d.textures = f.textures.data(); d.images = f.images.data();
     d.image_bytes = f.image_bytes.data(); d.perlins = f.perlins.data(); d.lights = f.lights.data();
-    d.world = f.world; d.n_lights = f.n_lights; d.lights_is_list = f.lights_is_list; d.q_extent = f.q_extent;
+    d.world = f.world; d.n_lights = f.n_lights; d.lights_is_list = f.lights_is_list; d.q_extent = f.q_extent; d.uses_uv = f.uses_uv ? 1u : 0u; d._pad = 0;
 }
 
 int upload_scene(rt_scene* s) {
@@ -473,7 +473,7 @@ int upload_scene(rt_scene* s) {
     if ((rc = upload(s, f.image_bytes, &d.image_bytes))) return rc;
     if ((rc = upload(s, f.perlins, &d.perlins))) return rc;
     if ((rc = upload(s, f.lights, &d.lights))) return rc;
-    d.world = f.world; d.n_lights = f.n_lights; d.lights_is_list = f.lights_is_list; d.q_extent = f.q_extent;
+    d.world = f.world; d.n_lights = f.n_lights; d.lights_is_list = f.lights_is_list; d.q_extent = f.q_extent; d.uses_uv = f.uses_uv ? 1u : 0u; d._pad = 0;
     void* c = nullptr;
     HIP_TRY(hipMalloc(&c, C_WORDS * sizeof(unsigned long long)));
     s->allocs.push_back(c);

@@ -147,9 +147,10 @@ RT_DEV D3 lights_random(const DScene& S, D3 origin, Rng& g) {
         double r1 = g.next();
         double r2 = g.next();
         double z = 1.0 + r2 * (sqrt(1.0 - s.radius * s.radius / distance_squared) - 1.0);
-        double phi = 2.0 * D_PI * r1;
-        double x = cos(phi) * sqrt(1.0 - z * z);
-        double y = sin(phi) * sqrt(1.0 - z * z);
+        double sphi, cphi;
+        sincos_2pi(r1, sphi, cphi);
+        double x = cphi * sqrt(1.0 - z * z);
+        double y = sphi * sqrt(1.0 - z * z);
         return uvw.transform(d3(x, y, z));
     }
     return d3(1.0, 0.0, 0.0); // hittable.rs:54-56

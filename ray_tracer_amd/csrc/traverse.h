@@ -308,7 +308,8 @@ RT_DEV void set_face_normal(HitRec& h, D3 dir, D3 outward_normal) { // hittable.
     h.normal = h.front_face ? outward_normal : -outward_normal;
 }
 
-RT_DEV void finalize(const DScene& S, const WorldRay& w, double time, const Best& b, HitRec& h) {
+// want_uv = false skips the sphere's (u,v) (acos + atan2, sphere.rs:47-55) for callers that know nothing reads them.
+RT_DEV void finalize(const DScene& S, const WorldRay& w, double time, const Best& b, HitRec& h, bool want_uv = true) {
     RayD r;
     ray_in_context(S, w, b.ctx, r);
     const D3 o = d3(r.ox, r.oy, r.oz), d = d3(r.dx, r.dy, r.dz);
@@ -322,10 +323,12 @@ RT_DEV void finalize(const DScene& S, const WorldRay& w, double time, const Best
         D3 center = d3(s.c[0], s.c[1], s.c[2]) + time * d3(s.dc[0], s.dc[1], s.dc[2]);
         D3 outward_normal = (h.p - center) / s.radius;
         set_face_normal(h, d, outward_normal);
-        double theta = acos(-outward_normal.y); // sphere.rs:47-55
-        double phi = atan2(-outward_normal.z, outward_normal.x) + D_PI;
-        h.u = phi / (2.0 * D_PI);
-        h.v = theta / D_PI;
+        if (want_uv) {
+            double theta = acos(-outward_normal.y); // sphere.rs:47-55
+            double phi = atan2(-outward_normal.z, outward_normal.x) + D_PI;
+            h.u = phi / (2.0 * D_PI);
+            h.v = theta / D_PI;
+        }
         h.mat = s.mat;
     } else if (kind == RT_REF_QUAD) { // quad.rs:95-108
         const DQuad* q = S.quads + idx;
