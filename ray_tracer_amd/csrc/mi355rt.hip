@@ -207,6 +207,9 @@ __global__ __launch_bounds__(BLOCK) void raygen_kernel(CamD cam, BatchGeom bg, P
     ps.queue[0][p] = p;
 }
 
+// MEDIA = false: the scene holds no constant medium, so the nested boundary queries and the random draw inside
+// traversal are compiled out (fewer registers, one more wave per SIMD).
+template <bool MEDIA>
 __global__ __launch_bounds__(BLOCK) void extend_kernel(DScene S, PathState ps, int qsel, unsigned long long seed, BatchGeom bg, int32_t image_width) {
     __shared__ uint32_t s_stack[STACK_MAX * BLOCK];
     uint32_t* stk = s_stack + threadIdx.x;
@@ -233,7 +236,7 @@ __global__ __launch_bounds__(BLOCK) void extend_kernel(DScene S, PathState ps, i
             int32_t i = bg.x0 + (int32_t)(pix % (uint32_t)bg.tw);
             int32_t j = bg.y0 + (int32_t)(pix / (uint32_t)bg.tw);
             Rng g{seed, 0u, (uint32_t)(j * image_width + i), (uint32_t)(bg.sample0 + (int32_t)s_local), rec->rng_index};
-            traverse<true, false, true>(S, S.world, r, 0, w, time, 0.001, b, stk, 0, &g, nn, np); // Interval::new(0.001, INFINITY) (camera.rs:258)
+            traverse<MEDIA, false, true>(S, S.world, r, 0, w, time, 0.001, b, stk, 0, &g, nn, np); // Interval::new(0.001, INFINITY) (camera.rs:258)
             rec->hit_t = b.t;
             rec->hit_ref = b.ref;
             rec->hit_ctx = b.ctx;
@@ -408,7 +411,8 @@ int pick_grid(rt_scene* s) {
     int per_cu = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, closest_hit_kernel<false, true>, BLOCK, 0));
     int per_cu2 = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, extend_kernel, BLOCK, 0));
+    if (s->flat.has_medium) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, extend_kernel<true>, BLOCK, 0));
+    else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, extend_kernel<false>, BLOCK, 0));
     int per_cu3 = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu3, shade_kernel, BLOCK, 0));
     s->grid_blocks = prop.multiProcessorCount * std::max(1, per_cu);      // batched closest hit (general kernel)
@@ -621,7 +625,8 @@ int render_impl(rt_scene* s, const rt_camera* cam, uint64_t seed, const rt_work*
                                        s->d_counters + C_NODES, s->fast_spill, env_int("MI355RT_REFILL", REFILL_THRESHOLD),
                                        env_int("MI355RT_VOTE", LEAF_VOTE), env_int("MI355RT_CHUNK", 0), env_int("MI355RT_POP_TRIPS", POP_TRIPS));
                 } else {
-                    hipLaunchKernelGGL(extend_kernel, dim3(blocks), dim3(BLOCK), 0, st, s->dev, ps, qsel, (unsigned long long)seed, bg, cam->image_width);
+                    hipLaunchKernelGGL(s->flat.has_medium ? extend_kernel<true> : extend_kernel<false>, dim3(blocks), dim3(BLOCK), 0, st, s->dev, ps, qsel,
+                                       (unsigned long long)seed, bg, cam->image_width);
                 }
                 hipLaunchKernelGGL(shade_kernel, dim3(sblocks), dim3(BLOCK), 0, st, s->dev, cd, ps, qsel, (unsigned long long)seed, bg, bounce == cam->max_depth - 1 ? 1 : 0);
                 hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, st, s->d_counters);
