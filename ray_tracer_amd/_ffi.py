@@ -166,12 +166,33 @@ class RtError(RuntimeError):
         self.message = message
 
 
+def _share_torch_hip_runtime() -> None:
+    """One HIP runtime per process.  PyTorch wheels carry their own libamdhip64.so; if this library pulled in the
+    system's copy first and torch initialised afterwards, the process would hold two runtimes (observed: torch then
+    reports hipErrorNoDevice).  When torch is installed its copy is loaded first, without importing torch, and
+    libmi355rt.so binds to it through the shared soname."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass  # fall back to the system runtime
+
+
 def _load() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: the HIP extension has not been built. "
             "Run `python -c 'import __graft_entry__ as g; g.build()'` (or `make -C ray_tracer_amd/csrc`). "
             "ray_tracer_amd has no CPU fallback.")
+    _share_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol

@@ -143,3 +143,33 @@ def test_small_workspace_batches(monkeypatch):
     finally:
         del os.environ["MI355RT_MAX_PATHS"]
     assert np.allclose(small, full, rtol=1e-12, atol=1e-12, equal_nan=True)
+
+
+def test_render_device_entry_point_with_rank_units_on_a_stream():
+    """rt_render_device (device accumulator, caller's HIP stream): what every rank of a multi-GPU job calls.
+    The units of a 4-rank stratum split and of a 3-rank tile split, rendered one after the other into one
+    device accumulator on a side stream, must give the frame rt_render returns."""
+    import torch
+    from ray_tracer_amd import parallel
+    world, lights, cam = scenes.cornell_box(image_width=48, samples_per_pixel=16, max_depth=10)
+    desc = rt.SceneDesc.from_world(world, lights)
+    gpu = rt.Scene(desc)
+    assert torch.cuda.is_available()
+    c = cam.to_struct()
+    d = O.camera_initialize(c)
+    full = gpu.render(c, seed=11)
+    stream = torch.cuda.Stream()
+    for mode, ranks in (("strata", 4), ("tiles", 3)):
+        acc = torch.zeros((d.image_height, c.image_width, 3), dtype=torch.float64, device="cuda")
+        with torch.cuda.stream(stream):
+            for rank in range(ranks):
+                for w in parallel.partition_frame(c.image_width, d.image_height, d.sqrt_spp * d.sqrt_spp, rank, ranks, mode=mode):
+                    gpu.render_device(c, acc, seed=11, work=w, stream=stream.cuda_stream)
+        stream.synchronize()
+        assert np.allclose(acc.cpu().numpy(), full, rtol=1e-12, atol=1e-12, equal_nan=True), mode
+    # the single-process form of the distributed driver (no process group): same frame
+    acc = torch.zeros((d.image_height, c.image_width, 3), dtype=torch.float64, device="cuda")
+    parallel.render_distributed(lambda w, a: gpu.render_device(c, a, seed=11, work=w, stream=torch.cuda.current_stream().cuda_stream),
+                                acc, c.image_width, d.image_height, d.sqrt_spp * d.sqrt_spp)
+    torch.cuda.synchronize()
+    assert np.allclose(acc.cpu().numpy(), full, rtol=1e-12, atol=1e-12, equal_nan=True)
