@@ -13,11 +13,12 @@ using namespace rt_host;
 static void usage() {
     std::fprintf(stderr,
                  "usage: rt_cli --scene book1_final|quads|simple_light|cornell_box|cornell_smoke\n"
+                 "                     |obj_mesh|obj_model (with --obj file.obj)\n"
                  "              [--width W] [--spp N] [--depth D] [--seed S] [--out file.ppm|-] [--describe]\n");
 }
 
 int main(int argc, char** argv) {
-    std::string scene = "cornell_box", out;
+    std::string scene = "cornell_box", out, obj;
     int width = 0, spp = 0, depth = 0;
     uint64_t seed_ = 0;
     bool describe = false;
@@ -30,6 +31,7 @@ int main(int argc, char** argv) {
         else if (a == "--depth") depth = std::atoi(next());
         else if (a == "--seed") seed_ = std::strtoull(next(), nullptr, 10);
         else if (a == "--out") out = next();
+        else if (a == "--obj") obj = next();
         else if (a == "--describe") describe = true;
         else { usage(); return 2; }
     }
@@ -40,6 +42,7 @@ int main(int argc, char** argv) {
         else if (scene == "simple_light") s = simple_light(seed_);
         else if (scene == "cornell_box") s = cornell_box();
         else if (scene == "cornell_smoke") s = cornell_smoke();
+        else if ((scene == "obj_mesh" || scene == "obj_model") && !obj.empty()) s = obj_scene(obj, scene == "obj_model");
         else { usage(); return 2; }
         if (width > 0) s.cam.image_width = width;
         if (spp > 0) s.cam.samples_per_pixel = spp;

@@ -10,6 +10,9 @@
 #define MI355RT_HOST_HPP
 
 #include <algorithm>
+#include <array>
+#include <fstream>
+#include <sstream>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -141,6 +144,63 @@ struct TriangleSet : Hittable { // Mesh (mesh.rs:95-183, bvh = true) / ObjModel 
     std::vector<rt_triangle> triangles; MaterialPtr mat; bool bvh;
     TriangleSet(std::vector<rt_triangle> t, MaterialPtr m, bool b) : triangles(std::move(t)), mat(m), bvh(b) {}
 };
+
+// Minimal Wavefront OBJ reader for mesh.rs:101-167 / obj_loader.rs:21-83.  The reference goes through the
+// third-party crate tobj (triangulate + single_index); what reaches the hot path is a triangle list whose
+// positions went through f32 (mesh.rs:137-153 widens them to f64).  Kept here: `v` lines parsed to f32,
+// faces fan-triangulated (v0, v_i, v_i+1), negative indices relative to the end.  Parity with tobj on real
+// assets is unpinned: the reference ships no model file.
+inline std::vector<rt_triangle> load_obj_triangles(const std::string& path) {
+    std::ifstream in(path);
+    if (!in) throw std::runtime_error(path + ": cannot open");
+    std::vector<std::array<float, 3>> pos;
+    std::vector<rt_triangle> tris;
+    std::string line;
+    while (std::getline(in, line)) {
+        std::istringstream ls(line);
+        std::string tag;
+        if (!(ls >> tag)) continue;
+        if (tag == "v") {
+            double x, y, z;
+            if (!(ls >> x >> y >> z)) throw std::runtime_error(path + ": malformed vertex line: " + line);
+            pos.push_back({(float)x, (float)y, (float)z});
+        } else if (tag == "f") {
+            std::vector<long> idx;
+            std::string tok;
+            while (ls >> tok) {
+                const long i = std::stol(tok.substr(0, tok.find('/')));
+                idx.push_back(i > 0 ? i - 1 : (long)pos.size() + i);
+            }
+            for (size_t k = 1; k + 1 < idx.size(); ++k) {
+                const long f[3] = {idx[0], idx[k], idx[k + 1]};
+                rt_triangle t{};
+                for (int c = 0; c < 3; ++c) {
+                    if (f[c] < 0 || f[c] >= (long)pos.size()) throw std::runtime_error(path + ": face index out of range");
+                    double* dst = c == 0 ? t.v0 : (c == 1 ? t.v1 : t.v2);
+                    for (int a = 0; a < 3; ++a) dst[a] = (double)pos[(size_t)f[c]][a];
+                }
+                t.mat = -1;
+                tris.push_back(t);
+            }
+        }
+    }
+    return tris;
+}
+// Mesh::from_obj (mesh.rs:101-167): a BVH over the triangles of the file.
+inline std::shared_ptr<TriangleSet> mesh_from_obj(const std::string& path, MaterialPtr mat) {
+    return std::make_shared<TriangleSet>(load_obj_triangles(path), mat, true);
+}
+// ObjModel::load (obj_loader.rs:21-83): p * scale + offset per component, linear scan over the triangles.
+inline std::shared_ptr<TriangleSet> obj_model_load(const std::string& path, MaterialPtr mat, double scale, Vec3 offset) {
+    std::vector<rt_triangle> t = load_obj_triangles(path);
+    for (rt_triangle& tr : t)
+        for (int a = 0; a < 3; ++a) {
+            tr.v0[a] = tr.v0[a] * scale + offset.e[a];
+            tr.v1[a] = tr.v1[a] * scale + offset.e[a];
+            tr.v2[a] = tr.v2[a] * scale + offset.e[a];
+        }
+    return std::make_shared<TriangleSet>(std::move(t), mat, false);
+}
 
 inline std::shared_ptr<HittableList> box_new(Point3 a, Point3 b, MaterialPtr mat) { // quad.rs:139-193
     auto sides = std::make_shared<HittableList>();

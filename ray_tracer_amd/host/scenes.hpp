@@ -139,5 +139,16 @@ inline SceneTuple cornell_smoke(int width = 600, int spp = 200, int depth = 50) 
     return {world_bvh, lights, cornell_camera(width, spp, depth)};
 }
 
+// test_obj_model-style scene (main.rs:790-862): an OBJ mesh (BVH) or ObjModel (linear scan) over a ground sphere.
+inline SceneTuple obj_scene(const std::string& path, bool as_model) {
+    auto world = mk<HittableList>();
+    world->add(mk<Sphere>(Point3(0.0, -1000.0, 0.0), 1000.0, mk<Lambertian>(Color(0.5, 0.5, 0.5))));
+    auto mat = mk<Lambertian>(Color(0.7, 0.3, 0.2));
+    if (as_model) world->add(obj_model_load(path, mat, 1.0, Vec3(0.0, 0.0, 0.0)));
+    else world->add(mesh_from_obj(path, mat));
+    Camera cam = sky_camera(30.0, Point3(3.0, 2.0, 5.0), Point3(0.0, 0.7, 0.0));
+    return {world, nullptr, cam};
+}
+
 } // namespace rt_host
 #endif

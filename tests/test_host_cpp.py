@@ -44,9 +44,80 @@ def test_cpp_scene_description_matches_python(cli, name):
     assert got == want
 
 
+def _write_obj(path, subdiv=2):
+    """An OBJ file with shared vertices, quads (fan triangulation), v/vt/vn face tokens and negative indices."""
+    tris = scenes.icosphere_mesh(subdiv, seed=4) * 1.5 + np.array([-0.75, 0.0, -0.75])
+    verts, index, faces = [], {}, []
+    for t in tris:
+        f = []
+        for v in t:
+            key = tuple(np.float32(v).tolist())
+            if key not in index:
+                index[key] = len(verts)
+                verts.append(key)
+            f.append(index[key] + 1)
+        faces.append(f)
+    with open(path, "w") as fh:
+        fh.write("# generated\n")
+        for v in verts:
+            fh.write("v %r %r %r\n" % v)
+        for k, f in enumerate(faces):
+            if k % 3 == 0:
+                fh.write("f %d/1/1 %d/2/2 %d/3/3\n" % tuple(f))
+            elif k % 3 == 1:
+                fh.write("f %d %d %d\n" % tuple(i - len(verts) - 1 for i in f))  # relative to the end
+            else:
+                fh.write("f %d//1 %d//1 %d//1\n" % tuple(f))
+        n = len(verts)
+        fh.write("v 2 0 2\nv 3 0 2\nv 3 0 3\nv 2 0 3\nf %d %d %d %d\n" % (n + 1, n + 2, n + 3, n + 4))  # one quad
+    return len(faces) + 2
+
+
+def _py_obj_scene(path, as_model):
+    world = rta.HittableList()
+    world.add(rta.Sphere(rta.Point3(0.0, -1000.0, 0.0), 1000.0, rta.Lambertian(rta.Color(0.5, 0.5, 0.5))))
+    mat = rta.Lambertian(rta.Color(0.7, 0.3, 0.2))
+    world.add(rta.ObjModel.load(path, mat, 1.0, rta.Point3(0.0, 0.0, 0.0)) if as_model else rta.Mesh.from_obj(path, mat))
+    cam = rta.Camera()
+    cam.aspect_ratio, cam.image_width, cam.samples_per_pixel, cam.max_depth = 16.0 / 9.0, 400, 100, 50
+    cam.background = rta.Color(0.70, 0.80, 1.00)
+    cam.vfov, cam.lookfrom, cam.lookat, cam.vup = 30.0, rta.Point3(3.0, 2.0, 5.0), rta.Point3(0.0, 0.7, 0.0), rta.Vec3(0.0, 1.0, 0.0)
+    cam.defocus_angle = 0.0
+    return world, None, cam
+
+
+@pytest.mark.parametrize("kind", ["obj_mesh", "obj_model"])
+def test_cpp_obj_reader_matches_python_reader(cli, tmp_path, kind):
+    path = str(tmp_path / "m.obj")
+    n_tris = _write_obj(path)
+    out = subprocess.run([cli, "--scene", kind, "--obj", path, "--describe"], check=True, capture_output=True, text=True).stdout
+    got = json.loads(out)
+    world, lights, _ = _py_obj_scene(path, kind == "obj_model")
+    desc = SceneDesc.from_world(world, lights)
+    info = Scene(desc, host_only=True).info()
+    assert got["triangles"] == n_tris == desc.struct.n_triangles
+    assert got["nodes"] == info.n_nodes and got["lists"] == info.n_lists and got["max_stack"] == info.max_stack
+    missing = subprocess.run([cli, "--scene", kind, "--obj", str(tmp_path / "none.obj"), "--describe"], capture_output=True, text=True)
+    assert missing.returncode == 1 and "cannot open" in missing.stderr
+
+
 def test_cpp_cli_rejects_unknown_scene(cli):
     r = subprocess.run([cli, "--scene", "nope"], capture_output=True, text=True)
     assert r.returncode == 2 and "usage" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["obj_mesh", "obj_model"])
+def test_cpp_obj_render_equals_python_render(cli, tmp_path, kind):
+    path = str(tmp_path / "m.obj")
+    _write_obj(path)
+    out_cpp, out_py = str(tmp_path / "cpp.ppm"), str(tmp_path / "py.ppm")
+    subprocess.run([cli, "--scene", kind, "--obj", path, "--seed", "3", "--width", "64", "--spp", "4", "--depth", "6", "--out", out_cpp],
+                   check=True, capture_output=True, timeout=120)
+    world, lights, cam = _py_obj_scene(path, kind == "obj_model")
+    cam.image_width, cam.samples_per_pixel, cam.max_depth = 64, 4, 6
+    cam.render(world, lights, seed=3, out=out_py)
+    assert open(out_cpp, "rb").read() == open(out_py, "rb").read()
 
 
 @pytest.mark.gpu
