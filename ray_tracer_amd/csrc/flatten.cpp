@@ -109,15 +109,31 @@ uint32_t build_bvh(std::vector<Item>& items, size_t start, size_t end, DNode* no
         widen(items[start].box.b, wn.lb);
         widen(items[start + 1].box.b, wn.rb);
     } else {
-        std::vector<uint32_t> order(span);
-        std::iota(order.begin(), order.end(), 0u);
+        // Stable sort by the minimum of the node's longest axis (bvh.rs:47-58, comparators bvh.rs:79-115).  The keys
+        // are pulled out next to the item numbers so the sort runs over 16-byte records, and a large span is sorted
+        // in slices on several threads and merged: both keep equal keys in their incoming order.
+        struct Key { double k; uint32_t i; };
+        std::vector<Key> order(span);
         const Item* base_items = items.data() + start;
-        std::stable_sort(order.begin(), order.end(), [base_items, axis](uint32_t a, uint32_t b) {
-            return base_items[a].box.b[2 * axis] < base_items[b].box.b[2 * axis];
-        });
+        for (size_t i = 0; i < span; ++i) order[i] = Key{base_items[i].box.b[2 * axis], (uint32_t)i};
+        auto less = [](const Key& a, const Key& b) { return a.k < b.k; };
+        const size_t slices = (depth < 3 && span > (1u << 16)) ? (size_t)(8 >> depth) : 1;
+        if (slices > 1) {
+            std::vector<std::future<void>> jobs;
+            std::vector<size_t> cut(slices + 1);
+            for (size_t s = 0; s <= slices; ++s) cut[s] = span * s / slices;
+            for (size_t s = 0; s < slices; ++s)
+                jobs.push_back(std::async(std::launch::async, [&, s]() { std::stable_sort(order.begin() + cut[s], order.begin() + cut[s + 1], less); }));
+            for (auto& j : jobs) j.get();
+            for (size_t width = 1; width < slices; width *= 2)
+                for (size_t s = 0; s + width < slices; s += 2 * width)
+                    std::inplace_merge(order.begin() + cut[s], order.begin() + cut[s + width], order.begin() + cut[std::min(s + 2 * width, slices)], less);
+        } else {
+            std::stable_sort(order.begin(), order.end(), less);
+        }
         {
             std::vector<Item> sorted(span);
-            for (size_t i = 0; i < span; ++i) sorted[i] = base_items[order[i]];
+            for (size_t i = 0; i < span; ++i) sorted[i] = base_items[order[i].i];
             std::copy(sorted.begin(), sorted.end(), items.begin() + start);
         }
         size_t mid = start + span / 2;
