@@ -5,16 +5,17 @@
 //   - 4-wide nodes: two levels of the binary tree in one record, boxes tested with a conservative f32
 //     slab test; children are entered nearest first.  Half as many dependent fetches per ray as the
 //     binary tree.  Two record formats: 128 bytes with f32 boxes (QNode), or 64 bytes with 8-bit
-//     boxes on a per-node grid (CQNode, QUANT = true).  On MI355X a divergent per-lane load costs the
-//     vector L1 about two cycles per (lane, 16-byte request) whether or not a lane's requests fall
-//     into one line (profiles/gather_probe.hip), and with f32 nodes that request rate is what bounds
-//     the kernel; the 64-byte record needs four requests per visit instead of seven;
+//     boxes on a per-node grid (CQNode, QUANT = true).  The kernel's time follows the number of
+//     128-byte lines a ray pulls through L2 from HBM (measured with FETCH_SIZE over four layouts),
+//     so the small record, sibling nodes sharing lines and one line per triangle are what made it
+//     faster; the 64-byte record also needs four 16-byte requests per visit instead of seven, which
+//     matters to the vector L1 (about two cycles per divergent request, profiles/gather_probe.hip);
 //   - stack entries carry the entry distance of the deferred child, so a subtree that the closest
 //     hit has overtaken since it was pushed is dropped at pop time without fetching its node;
 //     the newest 8 entries per lane sit in LDS, deeper ones spill to HBM (rare);
-//   - persistent waves with per-lane refill: a lane whose ray is finished takes the next ray from
-//     the global counter as soon as enough lanes of its wave are idle, instead of waiting for
-//     the slowest ray of a 64-ray chunk;
+//   - persistent waves with per-lane refill: a wave owns a private range of the batch (one global
+//     atomic per range) and a lane whose ray is finished takes the next ray of that range as soon
+//     as enough lanes of its wave are idle, instead of waiting for the slowest ray of a 64-ray chunk;
 //   - only (t, primitive) are produced here; the hit record is completed by finalize_hits_kernel,
 //     one coalesced pass over the batch.
 #ifndef RT_BVH_KERNEL_H
@@ -29,31 +30,13 @@ constexpr int REFILL_THRESHOLD = 40; // refill when fewer lanes than this are st
 constexpr int POP_TRIPS = 2;         // stack entries a lane may take (and discard) per iteration
 constexpr int LEAF_VOTE = 24;        // lanes that must stand on a primitive before the wave runs the intersector
 
-RT_DEV bool slab32(const float* b, const Ray32& q, float tmin_lo, float best_hi, float& near_t) {
-    const float nx = q.neg[0] ? b[1] : b[0], fx = q.neg[0] ? b[0] : b[1];
-    const float ny = q.neg[1] ? b[3] : b[2], fy = q.neg[1] ? b[2] : b[3];
-    const float nz = q.neg[2] ? b[5] : b[4], fz = q.neg[2] ? b[4] : b[5];
-    const float tnx = __builtin_fmaf(nx, q.inv[0], q.cn[0]), tfx = __builtin_fmaf(fx, q.inv[0], q.cf[0]);
-    const float tny = __builtin_fmaf(ny, q.inv[1], q.cn[1]), tfy = __builtin_fmaf(fy, q.inv[1], q.cf[1]);
-    const float tnz = __builtin_fmaf(nz, q.inv[2], q.cn[2]), tfz = __builtin_fmaf(fz, q.inv[2], q.cf[2]);
-    const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin_lo));
-    const float tf = fminf(fminf(tfx, tfy), fminf(tfz, best_hi));
-    near_t = tn;
-    return tn <= tf;
-}
-
 struct RayQueue {              // optional indirection: ray i of the launch is path queue[i]
     const uint32_t* queue;     // nullptr: identity
     const unsigned long long* count; // nullptr: use n
 };
 
-// RS = element stride of the batch arrays: 1 for the structure-of-arrays batches of the C ABI.  The
-// renderer hands in strided views of its 128-byte path records instead of copying rays out of them
-// (RS = doubles per record; out_t shares that stride, out_prim counts 32-bit words: 2 * RS).
-
 constexpr int LDS_STACK = 8;   // stack entries per lane held in LDS (power of two); deeper ones spill to HBM
 constexpr int FAST_WAVES = FAST_BLOCK / 64;
-constexpr uint32_t NO_NODE = 0xFFFFFFFFu;
 
 // Per-lane traversal stack: the newest LDS_STACK entries live in LDS ([slot][thread], 8 bytes each),
 // older ones in a per-thread column of `spill` (HBM, [entry][thread], coalesced across the wave).
@@ -101,6 +84,9 @@ struct LaneStack {
 RT_DEV float ubyte_f32(uint32_t w, int byte) { return (float)((w >> (8 * byte)) & 0xFFu); } // v_cvt_f32_ubyteN
 
 // PRIM: RT_REF_TRI / RT_REF_SPHERE / RT_REF_QUAD when every leaf has that kind, 0 for mixed leaves.
+// RS = element stride of the batch arrays: 1 for the structure-of-arrays batches of the C ABI.  The
+// renderer hands in strided views of its 128-byte path records instead of copying rays out of them
+// (RS = doubles per record; out_t shares that stride, out_prim counts 32-bit words: 2 * RS).
 template <int PRIM, bool COUNT, bool QUANT, int RS>
 __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, uint32_t root, rt_ray_batch rays,
                                                                        unsigned long long n_in, RayQueue rq, uint32_t opt, double tmin_default,
