@@ -266,3 +266,20 @@ def test_wide_nodes_fall_back_to_f32_when_one_primitive_dwarfs_the_rest():
     # a world that is not one BVH over primitives has no wide nodes
     world, lights, cam = scenes.cornell_box()
     assert len(rt.Scene(rt.SceneDesc.from_world(world, lights), host_only=True).wide_nodes()) == 0
+
+
+def test_reference_side_binding_in_integration_md_covers_the_header():
+    """The Rust `extern "C"` block a maintainer of the reference would add (it cannot be compiled here: no Rust
+    toolchain) must name every function of the header, and its #[repr(C)] structs must list the fields of the
+    ctypes structs in the same order."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    header = open(os.path.join(ROOT, "include", "mi355rt.h")).read()
+    declared = set(re.findall(r"^(?:int|double|const char\*)\s+(rt_[a-z0-9_]+)\s*\(", header, re.M))
+    rust_fns = set(re.findall(r"pub fn (rt_[a-z0-9_]+)\s*\(", text))
+    assert rust_fns == declared, rust_fns ^ declared
+    for name, body in re.findall(r"pub struct (rt_[a-z0-9_]+)\s*\{([^}]*)\}", text):
+        if name == "rt_scene":
+            continue
+        rust_fields = re.findall(r"pub ([a-z0-9_]+)\s*:", body)
+        c_fields = [f[0] for f in getattr(F, name)._fields_]
+        assert rust_fields == c_fields, (name, rust_fields, c_fields)
