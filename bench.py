@@ -173,17 +173,22 @@ def main() -> None:
             out["config"]["parity_vs_oracle"] = {"rays": int(mc), "prim_mismatch_not_tie": int((~same & ~tie).sum()),
                                                  "prim_mismatch_tie": int((~same & tie).sum())}
     if rank == 0 and world_size == 1 and not args.no_render:
-        out["render"] = _render_figure(rt, F, scenes, np, with_cpu=not args.no_cpu)
+        out["render"] = {name: _render_figure(rt, F, scenes, np, name, with_cpu=not args.no_cpu) for name in ("book2_final", "cornell_box")}
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
 
 
-def _render_figure(rt, F, scenes, np, with_cpu):
-    """Second half of the metric: camera samples/s of a full frame (the scene live at the reference's HEAD,
-    Cornell box with mixture-PDF light sampling, 600x600, depth 50) next to the oracle on a few rows of it."""
-    world, lights, cam = scenes.cornell_box(image_width=600, samples_per_pixel=100, max_depth=50)
+def _render_figure(rt, F, scenes, np, name, with_cpu):
+    """Second half of the metric: camera samples/s of a full frame next to the oracle on some rows of it.
+    book2_final: final_scene (main.rs:651-788), 800x800, depth 40 (BVHs, instances, media, textures);
+    cornell_box: the scene live at the reference's HEAD (main.rs:421-551), 600x600, depth 50, mixture PDF.
+    100 samples per pixel each (the reference's 10000 / 1000 only lengthen the run)."""
+    if name == "book2_final":
+        world, lights, cam = scenes.book2_final(image_width=800, samples_per_pixel=100, max_depth=40)
+    else:
+        world, lights, cam = scenes.cornell_box(image_width=600, samples_per_pixel=100, max_depth=50)
     desc = rt.SceneDesc.from_world(world, lights)
     gpu = rt.Scene(desc)
     c, d = cam.to_struct(), cam.derived()
@@ -193,12 +198,12 @@ def _render_figure(rt, F, scenes, np, with_cpu):
     t0 = time.perf_counter()
     accum = gpu.render(c, seed=1)
     wall = time.perf_counter() - t0
-    fig = {"metric": "camera samples/s", "scene": f"cornell_box {cam.image_width}x{d.image_height}, {n_strata} samples/pixel, depth {cam.max_depth}",
+    fig = {"metric": "camera samples/s", "scene": f"{name} {cam.image_width}x{d.image_height}, {n_strata} samples/pixel, depth {cam.max_depth}",
            "value": paths / wall, "unit": "samples/s", "ms_frame": 1e3 * wall, "device_ms": gpu.counters().ms_last_render}
     if with_cpu:
         import oracle_ffi as O
-        rows, threads = 120, min(16, os.cpu_count() or 1)
-        y0 = d.image_height // 2
+        rows, threads = (200 if name == "book2_final" else 600), min(16, os.cpu_count() or 1)
+        y0 = max(0, (d.image_height - rows) // 2)
         acc = np.zeros_like(accum)
         t0 = time.perf_counter()
         O.OracleScene(desc).render(c, seed=1, work=F.rt_work(0, y0, cam.image_width, y0 + rows, 0, n_strata), accum=acc, nthreads=threads)
