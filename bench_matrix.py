@@ -27,7 +27,7 @@ def main() -> None:
     ap.add_argument("--rays", type=int, default=1 << 24)
     ap.add_argument("--sample", type=int, default=1 << 16)
     ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--scenes", default="book1,spheres1e4,spheres1e6,soup,bunny")
+    ap.add_argument("--scenes", default="book1,spheres1e4,spheres1e6,soup,bunny,cornell,book2")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
 
@@ -56,6 +56,10 @@ def main() -> None:
             return scenes.random_spheres(1_000_000, seed=1)
         if name == "soup":
             return scenes.triangle_soup_scene(1 << 20, seed=2)
+        if name == "cornell":  # general kernel: flat list, instance, glass sphere (main.rs:421-551)
+            return scenes.cornell_box()[0]
+        if name == "book2":    # general kernel: two BVHs, lists, instances, constant media (main.rs:651-788)
+            return scenes.book2_final(seed=0)[0]
         if name == "bunny":
             return rt.Mesh(scenes.icosphere_mesh(6, seed=4), rt.Lambertian(rt.Color(0.5, 0.5, 0.5)))
         raise SystemExit(f"unknown scene {name}")
@@ -81,6 +85,8 @@ def main() -> None:
         b = [info.world_bounds[k] for k in range(6)]
         if name == "book1":  # look at the small spheres, not at the 1000-radius ground sphere's box
             b = [-11.0, 11.0, 0.0, 2.0, -11.0, 11.0]
+        if name == "book2":  # the room, not the 5000-radius fog boundary
+            b = [-1000.0, 1000.0, 0.0, 600.0, -1000.0, 1000.0]
         m = side * side
         hits = {"t": torch.empty(m, dtype=torch.float64, device=dev), "prim": torch.empty(m, dtype=torch.int32, device=dev)}
         for nm in ("u", "v", "nx", "ny", "nz", "px", "py", "pz"):
@@ -89,6 +95,9 @@ def main() -> None:
         hits["mat"] = torch.empty(m, dtype=torch.int32, device=dev)
         batches = {}
         o, d, tm = scenes.primary_rays(side, b)
+        if name == "cornell":  # look in through the open front (main.rs:536 puts the camera at z = -800), not at the back of the back wall
+            o[:, 2] = (b[4] + b[5]) - o[:, 2]
+            d[:, 2] = -d[:, 2]
         batches["A primary"] = to_dev(o, d, tm)
         o, d, tm = scenes.incoherent_rays(m, b, seed=3)
         batches["B incoherent"] = to_dev(o, d, tm)
@@ -134,11 +143,23 @@ def main() -> None:
             sdv = np.stack([rays[c][idx].cpu().numpy() for c in ("dx", "dy", "dz")], 1)
             st = rays["time"][idx].cpu().numpy()
             ref = cpu.closest_hit(so, sdv, time=st, nthreads=min(16, os.cpu_count() or 1))
-            tg = hits["t"][idx].cpu().numpy()
-            pg = hits["prim"][idx].cpu().numpy().astype(np.uint32)
-            t_same = int(np.sum((tg == ref["t"]) | (np.isinf(tg) & np.isinf(ref["t"]))))
+            if info.n_media:
+                # a medium's scattering distance is drawn from the counter RNG keyed by the ray's index in its
+                # batch: compare like with like by tracing the gathered sample as a batch of its own
+                srays = {c: rays[c][idx].contiguous() for c in rays}
+                shits = {c: torch.empty(k, dtype=hits[c].dtype, device=dev) for c in hits}
+                gpu.closest_hit_device(srays, shits, k, seed=0, flags=F.RT_HIT_ORDERED, stream=stream)
+                torch.cuda.synchronize()
+                tg = shits["t"].cpu().numpy()
+                pg = shits["prim"].cpu().numpy().astype(np.uint32)
+            else:
+                tg = hits["t"][idx].cpu().numpy()
+                pg = hits["prim"][idx].cpu().numpy().astype(np.uint32)
+            # a constant-medium hit goes through ln(U): device and glibc logarithms may differ in the last place
+            t_same = int(np.sum((tg == ref["t"]) | (np.isinf(tg) & np.isinf(ref["t"])) |
+                                (((ref["prim"] >> 28) == F.RT_REF_MEDIUM) & np.isclose(tg, ref["t"], rtol=1e-12, atol=0))))
             p_same = int(np.sum(pg == ref["prim"]))
-            rows.append({"scene": name, "prims": int(len(desc.arrays["spheres"]) + len(desc.arrays["triangles"])), "nodes": int(info.n_nodes),
+            rows.append({"scene": name, "prims": int(len(desc.arrays["spheres"]) + len(desc.arrays["triangles"]) + len(desc.arrays["quads"])), "nodes": int(info.n_nodes),
                          "batch": bname, "rays": m, "kernel_ms": float(np.mean(ms)), "step_ms": wall * 1e3,
                          "Mrays_per_s": m / wall / 1e6, "Mrays_per_s_kernel": m / (float(np.mean(ms)) * 1e-3) / 1e6, "hit_fraction": hit_frac,
                          "sample": k, "t_identical": t_same, "prim_identical": p_same, "build_s": build_s})
