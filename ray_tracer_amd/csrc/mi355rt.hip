@@ -86,6 +86,23 @@ __device__ __forceinline__ unsigned long long wave_fetch(unsigned long long* cou
 // serves same-address atomics at roughly 10 ns each, so one atomic per 64 rays alone would cap a kernel
 // near 6 G rays/s.  Up to 16 wave-loads per fetch, fewer when the batch is small, so that every wave
 // still gets several fetches.
+// Work distribution of the persistent kernels: wave w starts on chunk w without asking anybody (at launch
+// every wave of the grid would hit the counter at the same moment, and the last one in line waits tens of
+// microseconds); later chunks come from the shared counter, which then only sees staggered requests.
+struct WaveWork {
+    unsigned long long chunk, first_base, dynamic_base;
+    bool started;
+    __device__ __forceinline__ WaveWork(unsigned long long chunk_) : chunk(chunk_), started(false) {
+        const unsigned long long waves = (unsigned long long)gridDim.x * (blockDim.x / 64u);
+        first_base = ((unsigned long long)blockIdx.x * (blockDim.x / 64u) + (threadIdx.x >> 6)) * chunk;
+        dynamic_base = waves * chunk;
+    }
+    __device__ __forceinline__ unsigned long long next(unsigned long long* counter) {
+        if (!started) { started = true; return first_base; }
+        return dynamic_base + wave_fetch(counter, chunk);
+    }
+};
+
 __device__ __forceinline__ unsigned long long wave_chunk(unsigned long long n) {
     const unsigned long long waves = (unsigned long long)gridDim.x * (blockDim.x / 64u);
     const unsigned long long k = n / (waves * 8ull * 64ull);
@@ -100,8 +117,9 @@ __global__ __launch_bounds__(BLOCK) void closest_hit_kernel(DScene S, rt_ray_bat
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t nn = 0, np = 0;
     const unsigned long long chunk = wave_chunk(n);
+    WaveWork work(chunk);
     for (;;) {
-        const unsigned long long base = wave_fetch(&counters[C_WORK], chunk);
+        const unsigned long long base = work.next(&counters[C_WORK]);
         if (base >= n) break;
         for (unsigned long long off = 0; off < chunk; off += 64ull) {
         unsigned long long i = base + off + lane;
@@ -218,11 +236,25 @@ __global__ __launch_bounds__(BLOCK) void extend_kernel(DScene S, PathState ps, i
     const uint32_t* queue = ps.queue[qsel];
     uint32_t nn = 0, np = 0;
     const unsigned long long chunk = wave_chunk(n);
+#ifdef RT_PHASE_STATS
+    if (threadIdx.x < 8) s_step_cycles[threadIdx.x] = 0ull;
+    __syncthreads();
+    unsigned long long ph[4] = {0ull, 0ull, 0ull, 0ull}, pieces = 0ull; // wave cycles: work fetch, record load, traversal, write-back
+#define RT_PHASE(k) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ph[k] += now_ - t_ph; t_ph = now_; } while (0)
+    unsigned long long t_ph = __builtin_amdgcn_s_memtime();
+#else
+#define RT_PHASE(k) do { } while (0)
+#endif
+    WaveWork work(chunk);
     for (;;) {
-        const unsigned long long base = wave_fetch(&ps.counters[C_WORK], chunk);
+        const unsigned long long base = work.next(&ps.counters[C_WORK]);
+        RT_PHASE(0);
         if (base >= n) break;
         for (unsigned long long off = 0; off < chunk; off += 64ull) {
         unsigned long long q = base + off + lane;
+#ifdef RT_PHASE_STATS
+        if (base + off < n) ++pieces;
+#endif
         if (q < n) {
             uint32_t p = queue[q];
             PathRec* rec = ps.rec + p;
@@ -230,20 +262,32 @@ __global__ __launch_bounds__(BLOCK) void extend_kernel(DScene S, PathState ps, i
             RayD r;
             ray_in_context(S, w, 0, r);
             double time = rec->time;
+            RT_PHASE(1);
             Best b;
             b.t = D_INF; b.ref = RT_REF_NONE; b.ctx = 0;
             uint32_t s_local = p / bg.npix, pix = p - s_local * bg.npix;
             int32_t i = bg.x0 + (int32_t)(pix % (uint32_t)bg.tw);
             int32_t j = bg.y0 + (int32_t)(pix / (uint32_t)bg.tw);
             Rng g{seed, 0u, (uint32_t)(j * image_width + i), (uint32_t)(bg.sample0 + (int32_t)s_local), rec->rng_index};
-            traverse<MEDIA, false, true>(S, S.world, r, 0, w, time, 0.001, b, stk, 0, &g, nn, np); // Interval::new(0.001, INFINITY) (camera.rs:258)
+            traverse<MEDIA, false, true, !MEDIA>(S, S.world, r, 0, w, time, 0.001, b, stk, 0, &g, nn, np); // Interval::new(0.001, INFINITY) (camera.rs:258)
+            RT_PHASE(2);
             rec->hit_t = b.t;
             rec->hit_ref = b.ref;
             rec->hit_ctx = b.ctx;
             rec->rng_index = g.index;
+            RT_PHASE(3);
         }
         }
     }
+#ifdef RT_PHASE_STATS
+    if (lane == 0u) {
+        for (int k = 0; k < 4; ++k) atomicAdd(&ps.counters[16 + k], ph[k]);
+        atomicAdd(&ps.counters[20], pieces);
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) atomicAdd(&ps.counters[8 + threadIdx.x], s_step_cycles[threadIdx.x]);
+#endif
+#undef RT_PHASE
 }
 
 constexpr int SHADE_ROUNDS = 16; // wave-loads of paths whose survivors share one queue reservation
@@ -909,10 +953,14 @@ int rt_get_counters(rt_scene* s, rt_counters* out) {
         if (s->render_timed) { float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, s->ev_r0, s->ev_r1)); s->counters.ms_last_render = ms; }
         s->counters.render_rays = s->h_counters[C_RAYS];
         if (getenv("MI355RT_DEBUG")) {
+#ifdef RT_PHASE_STATS
+            std::fprintf(stderr, "[mi355rt] traversal step cycles: wide %llu exact %llu prim %llu list %llu xform %llu - %llu pop %llu\n", s->h_counters[8],
+                         s->h_counters[9], s->h_counters[10], s->h_counters[11], s->h_counters[12], s->h_counters[13], s->h_counters[14]);
+#endif
             std::fprintf(stderr, "[mi355rt] wave diag: iters %llu node_lanes %llu tri_phases %llu tri_lanes %llu pop_iters %llu pop_lanes %llu rounds %llu run_lanes %llu\n",
                          s->h_counters[8], s->h_counters[9], s->h_counters[10], s->h_counters[11], s->h_counters[12], s->h_counters[13], s->h_counters[14], s->h_counters[15]);
-            std::fprintf(stderr, "[mi355rt] wave cycles (s_memtime, summed over waves): refill %llu node %llu leaf %llu pop %llu\n", s->h_counters[16],
-                         s->h_counters[17], s->h_counters[18], s->h_counters[19]);
+            std::fprintf(stderr, "[mi355rt] wave cycles (s_memtime, summed over waves): refill %llu node %llu leaf %llu pop %llu (64-ray pieces %llu)\n", s->h_counters[16],
+                         s->h_counters[17], s->h_counters[18], s->h_counters[19], s->h_counters[20]);
         }
     }
     *out = s->counters;

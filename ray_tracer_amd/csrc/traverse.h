@@ -109,27 +109,68 @@ RT_DEV void test_primitive(const DScene& S, uint32_t ref, const RayD& ray, int32
     }
 }
 
-// Closest hit of `root` for the lane's ray over (tmin, best.t].  TOP = the world query
-// (constant media allowed); the nested boundary queries of a medium run with TOP = false.
-// `stk` points at this lane's column of the LDS stack, entries are BLOCK words apart.
-//
-// ORDERED = false is the reference's visit order on the exact f64 nodes.  ORDERED = true uses the
-// wide nodes: both child boxes are tested at the parent and the nearer child is entered first.
-// The closest hit is the same; only which of several primitives hit at exactly equal t is
-// reported may differ.  Subtrees that hold a constant medium always take the exact
-// reference-order path, because a medium draws a random number per visit
-// (constant_medium.rs:90) and whether it is visited must not depend on the traversal variant.
-template <bool TOP, bool COUNT, bool ORDERED>
+// ---- wave-uniform records --------------------------------------------------------------------------
+// When every active lane of a wave wants the same record (a flat world such as the Cornell box: every ray
+// tests every wall, in the same order), the record goes through the scalar cache into scalar registers: one
+// request instead of 64.  It matters more than the request count suggests.  A compute unit's vector L1
+// returns data in request order, and the same waves stream path records from HBM, so a vector load of a
+// perfectly cached wall was measured to wait ~1900 cycles behind other waves' misses; the scalar path does
+// not share that queue.
+RT_DEV bool wave_uniform(uint32_t x) {
+    return __builtin_amdgcn_ballot_w64(x != (uint32_t)__builtin_amdgcn_readfirstlane((int)x)) == 0ull;
+}
+RT_DEV uint32_t first_lane(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+template <typename T> RT_DEV T uniform_load(const T* p) { // p must be wave-uniform
+    static_assert(sizeof(T) % 4 == 0, "records are whole dwords");
+    typedef const uint32_t __attribute__((address_space(4))) * ConstWords;
+    ConstWords cp = (ConstWords)(uintptr_t)p;
+    union { T v; uint32_t w[sizeof(T) / 4]; } u;
+#pragma unroll
+    for (unsigned k = 0; k < sizeof(T) / 4; ++k) u.w[k] = cp[k];
+    return u.v;
+}
+RT_DEV void test_uniform_primitive(const DScene& S, uint32_t item, const RayD& ray, int32_t ctx, double time, double tmin, Best& best) {
+    const uint32_t k = item >> 28, i = item & 0x0FFFFFFFu; // wave-uniform
+    if (k == RT_REF_QUAD) {
+        const DQuad q = uniform_load(S.quads + i);
+        double t;
+        if (quad_eval(q, ray, t) && tmin <= t && t <= best.t) { best.t = t; best.ref = item; best.ctx = ctx; }
+    } else if (k == RT_REF_SPHERE) {
+        const DSphere sp = uniform_load(S.spheres + i);
+        double t;
+        if (sphere_test(sp, ray, time, tmin, best.t, t)) { best.t = t; best.ref = item; best.ctx = ctx; }
+    } else { // RT_REF_TRI
+        const DTri tr = uniform_load(S.tris + i);
+        double t, u, v;
+        if (tri_test(d3p(tr.v0), d3p(tr.v1), d3p(tr.v2), ray, tmin, best.t, t, u, v)) { best.t = t; best.ref = item; best.ctx = ctx; }
+    }
+}
+
+#ifdef RT_PHASE_STATS
+// wave cycles per kind of traversal step (stats build only): 0 wide/4-wide node, 1 exact node, 2 single primitive,
+// 3 list walk, 4 transform enter/leave, 5 medium bookkeeping, 6 pop
+__shared__ unsigned long long s_step_cycles[8];
+#define RT_STEP_BEGIN() const unsigned long long step_t0_ = __builtin_amdgcn_s_memtime()
+#define RT_STEP_END(k) do { if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) atomicAdd(&s_step_cycles[k], (unsigned long long)__builtin_amdgcn_s_memtime() - step_t0_); } while (0)
+#else
+#define RT_STEP_BEGIN() do { } while (0)
+#define RT_STEP_END(k) do { } while (0)
+#endif
+
+template <bool TOP, bool COUNT, bool ORDERED, bool WAVE_LISTS = true>
 __device__ __forceinline__ void traverse(const DScene& S, uint32_t root, RayD ray, int32_t ctx, const WorldRay& w,
                                          double time, double tmin, Best& best, uint32_t* stk, int sp0, Rng* rng,
                                          uint32_t& n_nodes, uint32_t& n_prims) {
     int sp = sp0;
     uint32_t cur = root;
+    const RayD entry_ray = ray;
+    const int32_t entry_ctx = ctx;
     for (;;) {
         const uint32_t kind = cur >> 28, idx = cur & 0x0FFFFFFFu;
         bool pop = true;
         bool wide_done = false;
         if (ORDERED && kind == RT_REF_NODE) {
+            RT_STEP_BEGIN();
             WNodeLoad wn;
             load_wnode(S.wnodes, idx, wn);
             if (wn.pad) { // root of a BVH without media: continue in its 4-wide copy
@@ -150,11 +191,13 @@ __device__ __forceinline__ void traverse(const DScene& S, uint32_t root, RayD ra
                 } else if (hl) { cur = wn.left; pop = false; }
                 else if (hr) { cur = wn.right; pop = false; }
             }
+            RT_STEP_END(0);
         }
         if (wide_done) {
         } else if (ORDERED && kind == REF_QNODE) {
             // 4-wide node: conservative f32 slab test of the four child boxes, nearest child first.  The
             // children may be anything (primitives, lists, instances, further nodes).
+            RT_STEP_BEGIN();
             const float4* row = reinterpret_cast<const float4*>(S.qnodes + idx);
             const float4 lox = row[0], loy = row[1], loz = row[2];
             const float4 hix = row[3], hiy = row[4], hiz = row[5];
@@ -192,7 +235,9 @@ __device__ __forceinline__ void traverse(const DScene& S, uint32_t root, RayD ra
                 cur = rf[0];
                 pop = false;
             }
+            RT_STEP_END(0);
         } else if (kind == RT_REF_NODE) {
+            RT_STEP_BEGIN();
             NodeLoad n;
             load_node(S.nodes, idx, n);
             if (COUNT) ++n_nodes;
@@ -204,12 +249,42 @@ __device__ __forceinline__ void traverse(const DScene& S, uint32_t root, RayD ra
                 cur = n.left;
                 pop = false;
             }
+            RT_STEP_END(1);
         } else if (kind == RT_REF_TRI || kind == RT_REF_SPHERE || kind == RT_REF_QUAD) {
+            RT_STEP_BEGIN();
             if (COUNT) ++n_prims;
             test_primitive(S, cur, ray, ctx, time, tmin, best);
+            RT_STEP_END(2);
         } else if (kind == RT_REF_LIST || kind == REF_LISTCONT) {
+            RT_STEP_BEGIN();
             uint32_t pos = 0;
             if (kind == REF_LISTCONT) { --sp; pos = stk[sp * BLOCK]; }
+            bool walked = false;
+            if (WAVE_LISTS && __builtin_amdgcn_ballot_w64(idx != first_lane(idx) || pos != first_lane(pos)) == 0ull) {
+                // every active lane stands at the same place of the same list
+                walked = true;
+                const uint32_t uidx = first_lane(idx);
+                uint32_t upos = first_lane(pos);
+                const DList ul = uniform_load(S.lists + uidx);
+                while (upos < ul.count) {
+                    const uint32_t item = uniform_load(S.list_items + ul.first + upos);
+                    const uint32_t ik = item >> 28;
+                    if (ik == RT_REF_TRI || ik == RT_REF_SPHERE || ik == RT_REF_QUAD) {
+                        if (COUNT) ++n_prims;
+                        test_uniform_primitive(S, item, ray, ctx, time, tmin, best);
+                        ++upos;
+                        continue;
+                    }
+                    if (upos + 1u < ul.count) {
+                        stk[sp * BLOCK] = upos + 1u; ++sp;
+                        stk[sp * BLOCK] = make_ref(REF_LISTCONT, uidx); ++sp;
+                    }
+                    cur = item;
+                    pop = false;
+                    break;
+                }
+            }
+            if (!walked) {
             const DList l = S.lists[idx];
             // Items are visited in list order (hittable_list.rs:46-57).  Primitives are tested right here;
             // the first item that is something else is entered through the stack, with the rest of the
@@ -246,17 +321,30 @@ __device__ __forceinline__ void traverse(const DScene& S, uint32_t root, RayD ra
                 pop = false;
                 break;
             }
+            }
+            RT_STEP_END(3);
         } else if (kind == RT_REF_XFORM) {
-            const DXform x = S.xforms[idx];
-            stk[sp * BLOCK] = make_ref(REF_POPX, (uint32_t)ctx); ++sp;
+            RT_STEP_BEGIN();
+            DXform x;
+            if (WAVE_LISTS && wave_uniform(idx)) x = uniform_load(S.xforms + first_lane(idx));
+            else x = S.xforms[idx];
+            // Leaving this transform restores the enclosing context.  When the entry below is already such a
+            // restore (this transform is the last thing its parent had to do: Translate(RotateY(box))), that
+            // one overrides ours, so ours is not pushed.
+            const bool restore_pending = sp > sp0 && (stk[(sp - 1) * BLOCK] >> 28) == REF_POPX;
+            if (!restore_pending) { stk[sp * BLOCK] = make_ref(REF_POPX, (uint32_t)ctx); ++sp; }
             apply_xform(x, ray);
             set_inverse(ray);
             ctx = (int32_t)idx + 1;
             cur = x.child;
             pop = false;
+            RT_STEP_END(4);
         } else if (kind == REF_POPX) {
+            RT_STEP_BEGIN();
             ctx = (int32_t)idx;
-            ray_in_context(S, w, ctx, ray);
+            if (WAVE_LISTS && ctx == entry_ctx) ray = entry_ray; // the ray this call was entered with, kept in registers
+            else ray_in_context(S, w, ctx, ray);
+            RT_STEP_END(4);
         } else if (kind == RT_REF_MEDIUM) {
             if constexpr (TOP) { // ConstantMedium::hit (constant_medium.rs:48-104)
                 const DMedium m = S.media[idx];
@@ -266,7 +354,7 @@ __device__ __forceinline__ void traverse(const DScene& S, uint32_t root, RayD ra
                 for (int pass = 0; pass < 2 && ok; ++pass) {
                     Best b; b.t = D_INF; b.ref = RT_REF_NONE; b.ctx = 0;
                     double lo = pass == 0 ? -D_INF : t1 + 0.0001; // Interval::UNIVERSE, then [rec1.t + 0.0001, inf)
-                    traverse<false, COUNT, ORDERED>(S, m.boundary, ray, ctx, w, time, lo, b, stk, sp, nullptr, n_nodes, n_prims);
+                    traverse<false, COUNT, ORDERED, WAVE_LISTS>(S, m.boundary, ray, ctx, w, time, lo, b, stk, sp, nullptr, n_nodes, n_prims);
                     if (b.ref == RT_REF_NONE) ok = false;
                     else if (pass == 0) t1 = b.t; else t2 = b.t;
                 }
@@ -287,9 +375,11 @@ __device__ __forceinline__ void traverse(const DScene& S, uint32_t root, RayD ra
             }
         }
         if (pop) {
+            RT_STEP_BEGIN();
             if (sp == sp0) break;
             --sp;
             cur = stk[sp * BLOCK];
+            RT_STEP_END(6);
         }
     }
 }
