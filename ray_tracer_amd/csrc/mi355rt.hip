@@ -28,7 +28,11 @@ using namespace rt;
 // ============================================================================ device code
 namespace {
 
+constexpr unsigned long long RANGES_PER_WAVE = 8ull; // work ranges a wave of a persistent kernel gets on average
 enum { C_WORK = 0, C_LIVE_IN = 1, C_LIVE_OUT = 2, C_NODES = 4, C_PRIMS = 5, C_RAYS = 6, C_WORDS = 24 };
+// Work counters of the general persistent kernels: one per XCD, each on a 128-byte line of its own, behind the
+// C_WORDS statistics words (the primitive-BVH kernel keeps its single counter C_WORK).
+constexpr int WORK_SLOTS = 8, WORK_STRIDE = 16, C_WORK_SLOTS = 32, C_ALLOC = C_WORK_SLOTS + WORK_SLOTS * WORK_STRIDE;
 
 struct CamD { // Camera after initialize() (camera.rs:30-42)
     rt_camera_derived d;
@@ -46,13 +50,14 @@ struct alignas(128) PathRec {
     double time;
     double beta[3];     // throughput
     double L[3];        // accumulated radiance
-    double hit_t;       // result of the last extend
-    uint32_t hit_ref;
-    int32_t hit_ctx;
     uint32_t rng_index; // draws taken so far from the path's stream
     uint32_t _pad;
+    double hit_t;       // result of the last extend: the last 16 bytes of the line, written with one store
+    uint32_t hit_ref;
+    int32_t hit_ctx;
 };
 static_assert(sizeof(PathRec) == 128, "a path is one cache line");
+static_assert(offsetof(PathRec, hit_t) == 112, "the hit block is one aligned 16-byte store");
 constexpr uint64_t PATH_DOUBLES = sizeof(PathRec) / sizeof(double);
 
 struct PathState {
@@ -86,28 +91,36 @@ __device__ __forceinline__ unsigned long long wave_fetch(unsigned long long* cou
 // serves same-address atomics at roughly 10 ns each, so one atomic per 64 rays alone would cap a kernel
 // near 6 G rays/s.  Up to 16 wave-loads per fetch, fewer when the batch is small, so that every wave
 // still gets several fetches.
-// Work distribution of the persistent kernels: wave w starts on chunk w without asking anybody (at launch
-// every wave of the grid would hit the counter at the same moment, and the last one in line waits tens of
-// microseconds); later chunks come from the shared counter, which then only sees staggered requests.
+// Work distribution of the persistent kernels.  The chip serves same-address atomics at roughly 10 ns each:
+// with one counter for all waves, one atomic per 64 rays caps a kernel near 6 G rays/s, and at launch, when
+// every wave asks at the same moment, the last in line waits tens of microseconds.  So a range is up to 16
+// wave-loads (fewer when the batch is small, so that every wave still gets several ranges); wave w starts on
+// range w without asking anybody; after that the waves of XCD x (workgroups are dealt round-robin over the 8
+// XCDs) take the ranges waves + 8k + x, k from a counter of their own.  Ranges are still handed out in queue
+// order, so at any moment the whole chip works on one window of the queue, which keeps the path records it
+// gathers close together in HBM (an even static split, every wave streaming through a region of its own,
+// was 8 % slower; so was looking at the counter with a plain load before paying for the last atomic).
 struct WaveWork {
-    unsigned long long chunk, first_base, dynamic_base;
+    unsigned long long n, len, first_base, dynamic_base;
+    uint32_t slot;
     bool started;
-    __device__ __forceinline__ WaveWork(unsigned long long chunk_) : chunk(chunk_), started(false) {
+    __device__ __forceinline__ WaveWork(unsigned long long n_) : n(n_), started(false) {
         const unsigned long long waves = (unsigned long long)gridDim.x * (blockDim.x / 64u);
-        first_base = ((unsigned long long)blockIdx.x * (blockDim.x / 64u) + (threadIdx.x >> 6)) * chunk;
-        dynamic_base = waves * chunk;
+        const unsigned long long wave_id = (unsigned long long)blockIdx.x * (blockDim.x / 64u) + (threadIdx.x >> 6);
+        const unsigned long long k = n / (waves * RANGES_PER_WAVE * 64ull);
+        len = 64ull * (k < 1ull ? 1ull : (k > 16ull ? 16ull : k));
+        first_base = wave_id * len;
+        slot = blockIdx.x % (uint32_t)WORK_SLOTS;
+        dynamic_base = (waves + slot) * len;
     }
-    __device__ __forceinline__ unsigned long long next(unsigned long long* counter) {
+    // Next range [base, base + len) of this wave; base >= n when the batch is finished.  `counters` is the
+    // scene's counter block (statistics words, then the work slots).
+    __device__ __forceinline__ unsigned long long next(unsigned long long* counters) {
         if (!started) { started = true; return first_base; }
-        return dynamic_base + wave_fetch(counter, chunk);
+        if (dynamic_base >= n) return n;
+        return dynamic_base + wave_fetch(counters + C_WORK_SLOTS + slot * WORK_STRIDE, 1ull) * (unsigned long long)WORK_SLOTS * len;
     }
 };
-
-__device__ __forceinline__ unsigned long long wave_chunk(unsigned long long n) {
-    const unsigned long long waves = (unsigned long long)gridDim.x * (blockDim.x / 64u);
-    const unsigned long long k = n / (waves * 8ull * 64ull);
-    return 64ull * (k < 1ull ? 1ull : (k > 16ull ? 16ull : k));
-}
 
 template <bool COUNT, bool ORDERED>
 __global__ __launch_bounds__(BLOCK) void closest_hit_kernel(DScene S, rt_ray_batch rays, unsigned long long n, rt_hit_batch hits,
@@ -116,10 +129,10 @@ __global__ __launch_bounds__(BLOCK) void closest_hit_kernel(DScene S, rt_ray_bat
     uint32_t* stk = s_stack + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t nn = 0, np = 0;
-    const unsigned long long chunk = wave_chunk(n);
-    WaveWork work(chunk);
+    WaveWork work(n);
+    const unsigned long long chunk = work.len;
     for (;;) {
-        const unsigned long long base = work.next(&counters[C_WORK]);
+        const unsigned long long base = work.next(counters);
         if (base >= n) break;
         for (unsigned long long off = 0; off < chunk; off += 64ull) {
         unsigned long long i = base + off + lane;
@@ -174,6 +187,7 @@ __global__ __launch_bounds__(BLOCK) void closest_hit_kernel(DScene S, rt_ray_bat
 
 __global__ void init_batch_kernel(unsigned long long* counters, unsigned long long npaths) {
     counters[C_WORK] = 0ull;
+    for (int k = 0; k < WORK_SLOTS; ++k) counters[C_WORK_SLOTS + k * WORK_STRIDE] = 0ull;
     counters[C_LIVE_IN] = npaths;
     counters[C_LIVE_OUT] = 0ull;
 }
@@ -188,9 +202,13 @@ __global__ void advance_kernel(unsigned long long* counters) {
     unsigned long long in = atomicExch(&counters[C_LIVE_IN], out);
     atomicAdd(&counters[C_RAYS], in);
     atomicExch(&counters[C_WORK], 0ull);
+    for (int k = 0; k < WORK_SLOTS; ++k) atomicExch(&counters[C_WORK_SLOTS + k * WORK_STRIDE], 0ull);
 }
 
-__global__ void reset_work_kernel(unsigned long long* counters) { counters[C_WORK] = 0ull; }
+__global__ void reset_work_kernel(unsigned long long* counters) {
+    counters[C_WORK] = 0ull;
+    for (int k = 0; k < WORK_SLOTS; ++k) counters[C_WORK_SLOTS + k * WORK_STRIDE] = 0ull;
+}
 
 __global__ __launch_bounds__(BLOCK) void raygen_kernel(CamD cam, BatchGeom bg, PathState ps, unsigned long long seed) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -227,15 +245,16 @@ __global__ __launch_bounds__(BLOCK) void raygen_kernel(CamD cam, BatchGeom bg, P
 
 // MEDIA = false: the scene holds no constant medium, so the nested boundary queries and the random draw inside
 // traversal are compiled out (fewer registers, one more wave per SIMD).
+// At least 3 waves per SIMD (168 registers): the variant with media sits within a few registers of that limit,
+// and one wave less costs it more than 10 %.
 template <bool MEDIA>
-__global__ __launch_bounds__(BLOCK) void extend_kernel(DScene S, PathState ps, int qsel, unsigned long long seed, BatchGeom bg, int32_t image_width) {
+__global__ __launch_bounds__(BLOCK, 3) void extend_kernel(DScene S, PathState ps, int qsel, unsigned long long seed, BatchGeom bg, int32_t image_width) {
     __shared__ uint32_t s_stack[STACK_MAX * BLOCK];
     uint32_t* stk = s_stack + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long n = ps.counters[C_LIVE_IN];
     const uint32_t* queue = ps.queue[qsel];
     uint32_t nn = 0, np = 0;
-    const unsigned long long chunk = wave_chunk(n);
 #ifdef RT_PHASE_STATS
     if (threadIdx.x < 8) s_step_cycles[threadIdx.x] = 0ull;
     __syncthreads();
@@ -245,9 +264,10 @@ __global__ __launch_bounds__(BLOCK) void extend_kernel(DScene S, PathState ps, i
 #else
 #define RT_PHASE(k) do { } while (0)
 #endif
-    WaveWork work(chunk);
+    WaveWork work(n);
+    const unsigned long long chunk = work.len;
     for (;;) {
-        const unsigned long long base = work.next(&ps.counters[C_WORK]);
+        const unsigned long long base = work.next(ps.counters);
         RT_PHASE(0);
         if (base >= n) break;
         for (unsigned long long off = 0; off < chunk; off += 64ull) {
@@ -271,10 +291,11 @@ __global__ __launch_bounds__(BLOCK) void extend_kernel(DScene S, PathState ps, i
             Rng g{seed, 0u, (uint32_t)(j * image_width + i), (uint32_t)(bg.sample0 + (int32_t)s_local), rec->rng_index};
             traverse<MEDIA, false, true, !MEDIA>(S, S.world, r, 0, w, time, 0.001, b, stk, 0, &g, nn, np); // Interval::new(0.001, INFINITY) (camera.rs:258)
             RT_PHASE(2);
-            rec->hit_t = b.t;
-            rec->hit_ref = b.ref;
-            rec->hit_ctx = b.ctx;
-            rec->rng_index = g.index;
+            uint4 hit_block; // hit_t, hit_ref, hit_ctx
+            hit_block.x = (uint32_t)__double2loint(b.t); hit_block.y = (uint32_t)__double2hiint(b.t);
+            hit_block.z = b.ref; hit_block.w = (uint32_t)b.ctx;
+            *reinterpret_cast<uint4*>(&rec->hit_t) = hit_block;
+            if (MEDIA) rec->rng_index = g.index; // only a constant medium draws during traversal (constant_medium.rs:90)
             RT_PHASE(3);
         }
         }
@@ -523,10 +544,10 @@ int upload_scene(rt_scene* s) {
     if ((rc = upload(s, f.lights, &d.lights))) return rc;
     d.world = f.world; d.n_lights = f.n_lights; d.lights_is_list = f.lights_is_list; d.q_extent = f.q_extent; d.uses_uv = f.uses_uv ? 1u : 0u; d._pad = 0;
     void* c = nullptr;
-    HIP_TRY(hipMalloc(&c, C_WORDS * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(&c, C_ALLOC * sizeof(unsigned long long)));
     s->allocs.push_back(c);
     s->d_counters = static_cast<unsigned long long*>(c);
-    HIP_TRY(hipMemset(c, 0, C_WORDS * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(c, 0, C_ALLOC * sizeof(unsigned long long)));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_counters), C_WORDS * sizeof(unsigned long long)));
     HIP_TRY(hipEventCreate(&s->ev_hit0));
     HIP_TRY(hipEventCreate(&s->ev_hit1));
@@ -568,6 +589,7 @@ uint64_t max_paths_setting() {
 int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit_batch* hits, uint64_t seed, uint32_t flags, hipStream_t st) {
     if (n == 0) return RT_OK;
     HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(unsigned long long), st)); // C_WORK
+    HIP_TRY(hipMemsetAsync(s->d_counters + C_WORK_SLOTS, 0, WORK_SLOTS * WORK_STRIDE * sizeof(unsigned long long), st));
     uint64_t waves = (n + 63) / 64;
     int blocks = (int)std::min<uint64_t>((uint64_t)s->grid_blocks, (waves + (BLOCK / 64) - 1) / (BLOCK / 64));
     HIP_TRY(hipEventRecord(s->ev_hit0, st));
@@ -973,7 +995,7 @@ int rt_reset_counters(rt_scene* s) {
     if (!s->host_only) {
         HIP_TRY(hipSetDevice(s->device));
         HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipMemset(s->d_counters, 0, C_WORDS * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(s->d_counters, 0, C_ALLOC * sizeof(unsigned long long)));
     }
     return RT_OK;
 }
