@@ -29,7 +29,7 @@ using namespace rt;
 namespace {
 
 constexpr unsigned long long RANGES_PER_WAVE = 8ull; // work ranges a wave of a persistent kernel gets on average
-enum { C_WORK = 0, C_LIVE_IN = 1, C_LIVE_OUT = 2, C_NODES = 4, C_PRIMS = 5, C_RAYS = 6, C_WORDS = 24 };
+enum { C_WORK = 0, C_LIVE_IN = 1, C_LIVE_OUT = 2, C_NODES = 4, C_PRIMS = 5, C_RAYS = 6, C_WORDS = 32 };
 // Work counters of the general persistent kernels: one per XCD, each on a 128-byte line of its own, behind the
 // C_WORDS statistics words (the primitive-BVH kernel keeps its single counter C_WORK).
 constexpr int WORK_SLOTS = 8, WORK_STRIDE = 16, C_WORK_SLOTS = 32, C_ALLOC = C_WORK_SLOTS + WORK_SLOTS * WORK_STRIDE;
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(BLOCK, 3) void extend_kernel(DScene S, PathState ps
             int32_t i = bg.x0 + (int32_t)(pix % (uint32_t)bg.tw);
             int32_t j = bg.y0 + (int32_t)(pix / (uint32_t)bg.tw);
             Rng g{seed, 0u, (uint32_t)(j * image_width + i), (uint32_t)(bg.sample0 + (int32_t)s_local), rec->rng_index};
-            traverse<MEDIA, false, true, !MEDIA>(S, S.world, r, 0, w, time, 0.001, b, stk, 0, &g, nn, np); // Interval::new(0.001, INFINITY) (camera.rs:258)
+            traverse<MEDIA, false, true, true, !MEDIA>(S, S.world, r, 0, w, time, 0.001, b, stk, 0, &g, nn, np); // Interval::new(0.001, INFINITY) (camera.rs:258)
             RT_PHASE(2);
             uint4 hit_block; // hit_t, hit_ref, hit_ctx
             hit_block.x = (uint32_t)__double2loint(b.t); hit_block.y = (uint32_t)__double2hiint(b.t);
@@ -326,6 +326,13 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(DScene S, CamD cam, PathSt
     unsigned long long rounds = n / (waves * 8ull * 64ull); // wave-loads per chunk: several chunks per wave, at most SHADE_ROUNDS
     rounds = rounds < 1ull ? 1ull : (rounds > (unsigned long long)SHADE_ROUNDS ? (unsigned long long)SHADE_ROUNDS : rounds);
     const unsigned long long chunk = rounds * 64ull;
+#ifdef RT_PHASE_STATS
+    unsigned long long ph[5] = {0ull, 0ull, 0ull, 0ull, 0ull}; // wave cycles: record load, hit record, material, write-back, queue
+#define RT_PHASE(k) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ph[k] += now_ - t_ph; t_ph = now_; } while (0)
+    unsigned long long t_ph = __builtin_amdgcn_s_memtime();
+#else
+#define RT_PHASE(k) do { } while (0)
+#endif
     for (unsigned long long base = wave_id * chunk; base < n; base += waves * chunk) {
         uint32_t kept = 0; // wave-uniform
         for (unsigned long long off = 0; off < chunk; off += 64ull) {
@@ -339,6 +346,7 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(DScene S, CamD cam, PathSt
                 D3 L = d3p(rec->L);
                 Best b;
                 b.t = rec->hit_t; b.ref = rec->hit_ref; b.ctx = rec->hit_ctx;
+                RT_PHASE(0);
                 if (b.ref == RT_REF_NONE) { // camera.rs:258-260
                     L = L + beta * d3p(cam.background);
                 } else {
@@ -346,6 +354,7 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(DScene S, CamD cam, PathSt
                     double time = rec->time;
                     HitRec h;
                     finalize(S, w, time, b, h, S.uses_uv != 0u); // only an image texture reads u,v (texture.rs:88-107)
+                    RT_PHASE(1);
                     uint32_t s_local = p / bg.npix, pix = p - s_local * bg.npix;
                     int32_t i = bg.x0 + (int32_t)(pix % (uint32_t)bg.tw);
                     int32_t j = bg.y0 + (int32_t)(pix / (uint32_t)bg.tw);
@@ -353,6 +362,7 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(DScene S, CamD cam, PathSt
                     D3 ray_dir = d3p(rec->d);
                     D3 no, nd;
                     alive = shade_hit(S, h, ray_dir, g, beta, L, no, nd);
+                    RT_PHASE(2);
                     if (alive) {
                         if (last_bounce) { // the next ray_color call has depth 0 and returns black (camera.rs:252-254)
                             L = L + beta * d3(0.0, 0.0, 0.0);
@@ -367,6 +377,7 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(DScene S, CamD cam, PathSt
                 }
                 rec->L[0] = L.x; rec->L[1] = L.y; rec->L[2] = L.z;
             }
+            RT_PHASE(3);
             const unsigned long long mask = __ballot(alive);
             if (alive) keep[kept + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = p;
             kept += (uint32_t)__popcll(mask);
@@ -379,7 +390,12 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(DScene S, CamD cam, PathSt
             for (uint32_t k = lane; k < kept; k += 64u) qout[slot_lo + k] = keep[k];
             __builtin_amdgcn_wave_barrier();
         }
+        RT_PHASE(4);
     }
+#ifdef RT_PHASE_STATS
+    if (lane == 0u) for (int k = 0; k < 5; ++k) atomicAdd(&ps.counters[24 + k], ph[k]);
+#endif
+#undef RT_PHASE
 }
 
 __global__ __launch_bounds__(BLOCK) void accumulate_kernel(PathState ps, BatchGeom bg, double* accum, int32_t image_width) {
@@ -976,6 +992,8 @@ int rt_get_counters(rt_scene* s, rt_counters* out) {
         s->counters.render_rays = s->h_counters[C_RAYS];
         if (getenv("MI355RT_DEBUG")) {
 #ifdef RT_PHASE_STATS
+            std::fprintf(stderr, "[mi355rt] shade wave cycles: record load %llu hit record %llu material %llu write-back %llu queue %llu\n", s->h_counters[24],
+                         s->h_counters[25], s->h_counters[26], s->h_counters[27], s->h_counters[28]);
             std::fprintf(stderr, "[mi355rt] traversal step cycles: wide %llu exact %llu prim %llu list %llu xform %llu - %llu pop %llu\n", s->h_counters[8],
                          s->h_counters[9], s->h_counters[10], s->h_counters[11], s->h_counters[12], s->h_counters[13], s->h_counters[14]);
 #endif

@@ -89,21 +89,24 @@ RT_DEV D3 texture_value(const DScene& S, int32_t tex, double u, double v, D3 p) 
 }
 
 // -------------------------------------------------------------------- lights
+// The light list is the same for every lane, so its entries and the primitives they name are read through
+// the scalar cache (uniform_load): a vector load of the same address by all lanes queues behind the path
+// records the compute unit is streaming from HBM.
 // pdf_value of one light for the ray (origin, direction, time 0) (quad.rs:117-131, sphere.rs:117-131).
-RT_DEV double light_pdf_one(const DScene& S, DLight l, D3 origin, D3 direction) {
+RT_DEV double light_pdf_one(const DScene& S, DLight l, D3 origin, D3 direction) { // `l` is wave-uniform
     RayD r;
     r.ox = origin.x; r.oy = origin.y; r.oz = origin.z;
     r.dx = direction.x; r.dy = direction.y; r.dz = direction.z;
     if (l.kind == RT_REF_QUAD) {
-        const DQuad* q = S.quads + l.index;
+        const DQuad q = uniform_load(S.quads + l.index);
         double t, al, be;
-        if (!quad_test(*q, r, 0.001, D_INF, t, al, be)) return 0.0;
+        if (!quad_test(q, r, 0.001, D_INF, t, al, be)) return 0.0;
         double distance_squared = t * t * length_squared(direction);
-        double cosine = fabs(dot(direction, d3p(q->n)) / length(direction)); // |.| makes the face flip irrelevant
-        return distance_squared / (cosine * q->area);
+        double cosine = fabs(dot(direction, d3p(q.n)) / length(direction)); // |.| makes the face flip irrelevant
+        return distance_squared / (cosine * q.area);
     }
     if (l.kind == RT_REF_SPHERE) {
-        const DSphere s = S.spheres[l.index];
+        const DSphere s = uniform_load(S.spheres + l.index);
         double t;
         if (!sphere_test(s, r, 0.0, 0.001, D_INF, t)) return 0.0;
         D3 center = d3(s.c[0], s.c[1], s.c[2]) + 0.0 * d3(s.dc[0], s.dc[1], s.dc[2]);
@@ -116,30 +119,26 @@ RT_DEV double light_pdf_one(const DScene& S, DLight l, D3 origin, D3 direction) 
 }
 
 RT_DEV double lights_pdf_value(const DScene& S, D3 origin, D3 direction) {
-    if (!S.lights_is_list) return light_pdf_one(S, S.lights[0], origin, direction);
+    if (!S.lights_is_list) return light_pdf_one(S, uniform_load(S.lights), origin, direction);
     double weight = 1.0 / (double)S.n_lights; // hittable_list.rs:67-76
     double sum = 0.0;
-    for (int32_t i = 0; i < S.n_lights; ++i) sum += weight * light_pdf_one(S, S.lights[i], origin, direction);
+    for (int32_t i = 0; i < S.n_lights; ++i) sum += weight * light_pdf_one(S, uniform_load(S.lights + i), origin, direction);
     return sum;
 }
 
-RT_DEV D3 lights_random(const DScene& S, D3 origin, Rng& g) {
-    DLight l = S.lights[0];
-    if (S.lights_is_list) { // hittable_list.rs:78-81
-        int32_t index = g.random_int(0, S.n_lights - 1);
-        l = S.lights[index];
-    }
-    if (l.kind == RT_REF_QUAD) { // quad.rs:133-136
-        const DQuad* q = S.quads + l.index;
+// random() of one light (quad.rs:133-136; sphere.rs:133-141, 57-67): two draws either way.
+RT_DEV D3 light_random_one(const DScene& S, DLight l, D3 origin, Rng& g) { // `l` is wave-uniform
+    if (l.kind == RT_REF_QUAD) {
+        const DQuad q = uniform_load(S.quads + l.index);
         double r1 = g.next();
-        D3 a = r1 * d3p(q->u);
+        D3 a = r1 * d3p(q.u);
         double r2 = g.next();
-        D3 b = r2 * d3p(q->v);
-        D3 p = d3p(q->q) + a + b;
+        D3 b = r2 * d3p(q.v);
+        D3 p = d3p(q.q) + a + b;
         return p - origin;
     }
-    if (l.kind == RT_REF_SPHERE) { // sphere.rs:133-141, 57-67
-        const DSphere s = S.spheres[l.index];
+    if (l.kind == RT_REF_SPHERE) {
+        const DSphere s = uniform_load(S.spheres + l.index);
         D3 center = d3(s.c[0], s.c[1], s.c[2]) + 0.0 * d3(s.dc[0], s.dc[1], s.dc[2]);
         D3 direction = center - origin;
         double distance_squared = length_squared(direction);
@@ -154,6 +153,20 @@ RT_DEV D3 lights_random(const DScene& S, D3 origin, Rng& g) {
         return uvw.transform(d3(x, y, z));
     }
     return d3(1.0, 0.0, 0.0); // hittable.rs:54-56
+}
+
+RT_DEV D3 lights_random(const DScene& S, D3 origin, Rng& g) {
+    if (!S.lights_is_list) return light_random_one(S, uniform_load(S.lights), origin, g);
+    const int32_t index = g.random_int(0, S.n_lights - 1); // hittable_list.rs:78-81
+    D3 out = d3(1.0, 0.0, 0.0);
+    // every lane picked its own light; the lights are visited one after the other (what the hardware does with a
+    // divergent branch anyway), each as a wave-uniform record
+    for (int32_t i = 0; i < S.n_lights; ++i) {
+        if (__builtin_amdgcn_ballot_w64(index == i) == 0ull) continue;
+        const DLight l = uniform_load(S.lights + i);
+        if (index == i) out = light_random_one(S, l, origin, g);
+    }
+    return out;
 }
 
 // ----------------------------------------------------------------- one bounce

@@ -157,7 +157,7 @@ __shared__ unsigned long long s_step_cycles[8];
 #define RT_STEP_END(k) do { } while (0)
 #endif
 
-template <bool TOP, bool COUNT, bool ORDERED, bool WAVE_LISTS = true>
+template <bool TOP, bool COUNT, bool ORDERED, bool WAVE_LISTS = true, bool KEEP_ENTRY_RAY = WAVE_LISTS>
 __device__ __forceinline__ void traverse(const DScene& S, uint32_t root, RayD ray, int32_t ctx, const WorldRay& w,
                                          double time, double tmin, Best& best, uint32_t* stk, int sp0, Rng* rng,
                                          uint32_t& n_nodes, uint32_t& n_prims) {
@@ -342,7 +342,7 @@ __device__ __forceinline__ void traverse(const DScene& S, uint32_t root, RayD ra
         } else if (kind == REF_POPX) {
             RT_STEP_BEGIN();
             ctx = (int32_t)idx;
-            if (WAVE_LISTS && ctx == entry_ctx) ray = entry_ray; // the ray this call was entered with, kept in registers
+            if (KEEP_ENTRY_RAY && ctx == entry_ctx) ray = entry_ray; // the ray this call was entered with, kept in registers
             else ray_in_context(S, w, ctx, ray);
             RT_STEP_END(4);
         } else if (kind == RT_REF_MEDIUM) {
@@ -354,7 +354,7 @@ __device__ __forceinline__ void traverse(const DScene& S, uint32_t root, RayD ra
                 for (int pass = 0; pass < 2 && ok; ++pass) {
                     Best b; b.t = D_INF; b.ref = RT_REF_NONE; b.ctx = 0;
                     double lo = pass == 0 ? -D_INF : t1 + 0.0001; // Interval::UNIVERSE, then [rec1.t + 0.0001, inf)
-                    traverse<false, COUNT, ORDERED, WAVE_LISTS>(S, m.boundary, ray, ctx, w, time, lo, b, stk, sp, nullptr, n_nodes, n_prims);
+                    traverse<false, COUNT, ORDERED, WAVE_LISTS, KEEP_ENTRY_RAY>(S, m.boundary, ray, ctx, w, time, lo, b, stk, sp, nullptr, n_nodes, n_prims);
                     if (b.ref == RT_REF_NONE) ok = false;
                     else if (pass == 0) t1 = b.t; else t2 = b.t;
                 }
