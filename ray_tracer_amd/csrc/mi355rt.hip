@@ -350,16 +350,18 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(DScene S, CamD cam, PathSt
                 if (b.ref == RT_REF_NONE) { // camera.rs:258-260
                     L = L + beta * d3p(cam.background);
                 } else {
-                    const WorldRay w = path_ray(ps, p);
+                    RayD wr; // the world ray, read together with the rest of the record
+                    wr.ox = rec->o[0]; wr.oy = rec->o[1]; wr.oz = rec->o[2];
+                    wr.dx = rec->d[0]; wr.dy = rec->d[1]; wr.dz = rec->d[2];
                     double time = rec->time;
                     HitRec h;
-                    finalize(S, w, time, b, h, S.uses_uv != 0u); // only an image texture reads u,v (texture.rs:88-107)
+                    finalize(S, wr, time, b, h, S.uses_uv != 0u); // only an image texture reads u,v (texture.rs:88-107)
                     RT_PHASE(1);
                     uint32_t s_local = p / bg.npix, pix = p - s_local * bg.npix;
                     int32_t i = bg.x0 + (int32_t)(pix % (uint32_t)bg.tw);
                     int32_t j = bg.y0 + (int32_t)(pix / (uint32_t)bg.tw);
                     Rng g{seed, 0u, (uint32_t)(j * cam.image_width + i), (uint32_t)(bg.sample0 + (int32_t)s_local), rec->rng_index};
-                    D3 ray_dir = d3p(rec->d);
+                    D3 ray_dir = d3(wr.dx, wr.dy, wr.dz);
                     D3 no, nd;
                     alive = shade_hit(S, h, ray_dir, g, beta, L, no, nd);
                     RT_PHASE(2);

@@ -50,9 +50,8 @@ RT_DEV void apply_xform(const DXform& x, RayD& r) {
 
 // Ray of this lane in context `ctx`: the world ray pushed through the chain of
 // transforms from the outermost to `ctx`, one rounding per reference operation.
-RT_DEV void ray_in_context(const DScene& S, const WorldRay& w, int32_t ctx, RayD& r) {
-    r.ox = w.ox[w.i]; r.oy = w.oy[w.i]; r.oz = w.oz[w.i];
-    r.dx = w.dx[w.i]; r.dy = w.dy[w.i]; r.dz = w.dz[w.i];
+// `r` holds the world ray (origin and direction) on entry.
+RT_DEV void world_to_context(const DScene& S, int32_t ctx, RayD& r) {
     if (ctx != 0) {
         int depth = S.xforms[ctx - 1].depth;
         for (int level = 1; level <= depth; ++level) {
@@ -62,6 +61,11 @@ RT_DEV void ray_in_context(const DScene& S, const WorldRay& w, int32_t ctx, RayD
         }
     }
     set_inverse(r);
+}
+RT_DEV void ray_in_context(const DScene& S, const WorldRay& w, int32_t ctx, RayD& r) {
+    r.ox = w.ox[w.i]; r.oy = w.oy[w.i]; r.oz = w.oz[w.i];
+    r.dx = w.dx[w.i]; r.dy = w.dy[w.i]; r.dz = w.dz[w.i];
+    world_to_context(S, ctx, r);
 }
 
 struct NodeLoad { double b[6]; uint32_t left, right, flags, pad; };
@@ -399,9 +403,9 @@ RT_DEV void set_face_normal(HitRec& h, D3 dir, D3 outward_normal) { // hittable.
 }
 
 // want_uv = false skips the sphere's (u,v) (acos + atan2, sphere.rs:47-55) for callers that know nothing reads them.
-RT_DEV void finalize(const DScene& S, const WorldRay& w, double time, const Best& b, HitRec& h, bool want_uv = true) {
-    RayD r;
-    ray_in_context(S, w, b.ctx, r);
+// `r` holds the world ray on entry (it is taken into the context of the hit here).
+RT_DEV void finalize(const DScene& S, RayD r, double time, const Best& b, HitRec& h, bool want_uv = true) {
+    world_to_context(S, b.ctx, r);
     const D3 o = d3(r.ox, r.oy, r.oz), d = d3(r.dx, r.dy, r.dz);
     const uint32_t kind = b.ref >> 28, idx = b.ref & 0x0FFFFFFFu;
     h.t = b.t;
@@ -459,6 +463,13 @@ RT_DEV void finalize(const DScene& S, const WorldRay& w, double time, const Best
         }
         c = x.parent;
     }
+}
+
+RT_DEV void finalize(const DScene& S, const WorldRay& w, double time, const Best& b, HitRec& h, bool want_uv = true) {
+    RayD r;
+    r.ox = w.ox[w.i]; r.oy = w.oy[w.i]; r.oz = w.oz[w.i];
+    r.dx = w.dx[w.i]; r.dy = w.dy[w.i]; r.dz = w.dz[w.i];
+    finalize(S, r, time, b, h, want_uv);
 }
 
 } // namespace rt
