@@ -16,6 +16,9 @@ namespace rt {
 constexpr uint32_t REF_QNODE = 7u;     // 4-wide node `index` of qnodes / cqnodes (ordered traversal only)
 constexpr uint32_t REF_LISTCONT = 8u;  // resume list `index` at the position stored one entry below
 constexpr uint32_t REF_POPX = 9u;      // leave a transform: restore context `index`
+constexpr uint32_t REF_QUADS = 10u;    // a list that is nothing but 2..16 consecutive quads (the six sides of a box): index =
+                                       // (count - 1) << 24 | first quad; stands in for the list in the 4-wide nodes, so the
+                                       // walk needs neither the list header nor its items
 constexpr uint32_t REF_OTHER = 15u;    // light-list member without pdf_value/random (hittable.rs:51-56 defaults)
 
 constexpr int STACK_MAX = 32;          // traversal stack entries per lane (LDS)

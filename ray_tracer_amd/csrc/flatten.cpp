@@ -556,7 +556,7 @@ struct Flattener {
                 const uint32_t child = base + (uint32_t)k++;
                 out_refs[j] = make_ref(REF_QNODE, child);
                 deepest = std::max(deepest, fill_qnode(child, RT_REF_INDEX(refs[j]), depth + 1));
-            } else out_refs[j] = refs[j];
+            } else out_refs[j] = quad_run(refs[j]);
         }
         QNode& q = f.qnodes[me];
         for (int j = 0; j < 4; ++j) {
@@ -569,6 +569,20 @@ struct Flattener {
             }
         }
         return (n - 1) + deepest; // up to n-1 siblings stay on the stack while one child is traversed
+    }
+    // A list of 2..16 quads stored one after the other (box_new: quad.rs:140-190 pushes the six sides in a row)
+    // is entered through a reference that names the quads directly.
+    uint32_t quad_run(uint32_t ref) {
+        if (RT_REF_KIND(ref) != RT_REF_LIST) return ref;
+        const DList& l = f.lists[RT_REF_INDEX(ref)];
+        if (l.count < 2u || l.count > 16u) return ref;
+        const uint32_t r0 = f.list_items[l.first];
+        if (RT_REF_KIND(r0) != RT_REF_QUAD || RT_REF_INDEX(r0) + l.count > (1u << 24)) return ref;
+        for (uint32_t k = 1; k < l.count; ++k)
+            if (f.list_items[l.first + k] != make_ref(RT_REF_QUAD, RT_REF_INDEX(r0) + k)) return ref;
+        const uint32_t run = make_ref(REF_QUADS, ((l.count - 1u) << 24) | RT_REF_INDEX(r0));
+        f.quad_runs.emplace_back(run, ref);
+        return run;
     }
     void add_empty_qnode() { // all four slots empty: never entered, keeps the index arithmetic simple
         QNode q{};

@@ -3,6 +3,7 @@
 #define RT_FLATTEN_H
 
 #include <string>
+#include <utility>
 #include <vector>
 #include "device_types.h"
 
@@ -30,6 +31,7 @@ struct FlatScene {
     std::vector<uint8_t> image_bytes;
     std::vector<rt_perlin> perlins;
     std::vector<DLight> lights;
+    std::vector<std::pair<uint32_t, uint32_t>> quad_runs; // (REF_QUADS reference used in the 4-wide nodes, the list it stands for)
     std::vector<Box> object_bounds; // bounding_box() of every object of the description
     uint32_t world = RT_REF_NONE;
     int32_t n_lights = -1;

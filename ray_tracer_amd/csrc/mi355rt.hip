@@ -822,7 +822,12 @@ int rt_scene_get_wide_nodes(const rt_scene* s, uint64_t first, uint64_t count, r
         o._pad = 0;
         for (int j = 0; j < 4; ++j) {
             // inner children are reported as RT_REF_NODE | wide index (the internal kind stays internal)
-            o.child[j] = RT_REF_KIND(q.child[j]) == REF_QNODE ? ((RT_REF_NODE << 28) | RT_REF_INDEX(q.child[j])) : q.child[j];
+            // and a run of quads as the list it stands for
+            uint32_t c = q.child[j];
+            if (RT_REF_KIND(c) == REF_QNODE) c = (RT_REF_NODE << 28) | RT_REF_INDEX(c);
+            else if (RT_REF_KIND(c) == REF_QUADS)
+                for (const auto& qr : s->flat.quad_runs) if (qr.first == c) { c = qr.second; break; }
+            o.child[j] = c;
             for (int a = 0; a < 3; ++a) {
                 o.box32[j][2 * a] = q.lo[a][j];
                 o.box32[j][2 * a + 1] = q.hi[a][j];

@@ -259,6 +259,27 @@ __device__ __forceinline__ void traverse(const DScene& S, uint32_t root, RayD ra
             if (COUNT) ++n_prims;
             test_primitive(S, cur, ray, ctx, time, tmin, best);
             RT_STEP_END(2);
+        } else if (ORDERED && kind == REF_QUADS) {
+            // 2..16 consecutive quads standing for the list that holds them: same tests in the same order
+            // (hittable_list.rs:46-57), without reading the list
+            RT_STEP_BEGIN();
+            const uint32_t first = idx & 0x00FFFFFFu, count = (idx >> 24) + 1u;
+            if (COUNT) n_prims += count;
+            if (WAVE_LISTS && wave_uniform(cur)) {
+                const uint32_t ufirst = first_lane(first), ucount = first_lane(count);
+                for (uint32_t k = 0; k < ucount; ++k) test_uniform_primitive(S, make_ref(RT_REF_QUAD, ufirst + k), ray, ctx, time, tmin, best);
+            } else {
+                uint32_t k = 0;
+                for (; k + 1u < count; k += 2u) { // pairs: both evaluated before either is accepted, acceptance in list order
+                    double ta, tb;
+                    const bool ia = quad_eval(S.quads[first + k], ray, ta);
+                    const bool ib = quad_eval(S.quads[first + k + 1u], ray, tb);
+                    if (ia && tmin <= ta && ta <= best.t) { best.t = ta; best.ref = make_ref(RT_REF_QUAD, first + k); best.ctx = ctx; }
+                    if (ib && tmin <= tb && tb <= best.t) { best.t = tb; best.ref = make_ref(RT_REF_QUAD, first + k + 1u); best.ctx = ctx; }
+                }
+                if (k < count) test_primitive(S, make_ref(RT_REF_QUAD, first + k), ray, ctx, time, tmin, best);
+            }
+            RT_STEP_END(3);
         } else if (kind == RT_REF_LIST || kind == REF_LISTCONT) {
             RT_STEP_BEGIN();
             uint32_t pos = 0;
