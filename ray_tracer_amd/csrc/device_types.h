@@ -115,7 +115,7 @@ struct alignas(8) DMedium {    // constant_medium.rs:14-18
 
 struct alignas(8) DMaterial {
     int32_t kind;
-    int32_t tex;
+    int32_t tex;               // -1: the texture is a solid colour and `albedo` holds it (SolidColor::value, texture.rs:28-30)
     double albedo[3];
     double fuzz;
     double ior;

@@ -88,6 +88,11 @@ RT_DEV D3 texture_value(const DScene& S, int32_t tex, double u, double v, D3 p) 
     }
 }
 
+RT_DEV D3 material_color(const DScene& S, const DMaterial& m, double u, double v, D3 p) {
+    if (m.tex < 0) return d3(m.albedo[0], m.albedo[1], m.albedo[2]);
+    return texture_value(S, m.tex, u, v, p);
+}
+
 // -------------------------------------------------------------------- lights
 // The light list is the same for every lane, so its entries and the primitives they name are read through
 // the scalar cache (uniform_load): a vector load of the same address by all lanes queues behind the path
@@ -174,7 +179,7 @@ RT_DEV D3 lights_random(const DScene& S, D3 origin, Rng& g) {
 RT_DEV bool shade_hit(const DScene& S, const HitRec& h, D3 ray_dir, Rng& g, D3& beta, D3& L, D3& next_o, D3& next_d) {
     const DMaterial m = S.materials[h.mat];
     if (m.kind == RT_MAT_DIFFUSE_LIGHT) { // material.rs:237-256: emits on the front face, never scatters
-        if (h.front_face) L = L + beta * texture_value(S, m.tex, h.u, h.v, h.p);
+        if (h.front_face) L = L + beta * material_color(S, m, h.u, h.v, h.p);
         return false;
     }
     if (m.kind == RT_MAT_METAL) { // material.rs:135-158; skip_pdf branch camera.rs:276-295
@@ -206,7 +211,7 @@ RT_DEV bool shade_hit(const DScene& S, const HitRec& h, D3 ray_dir, Rng& g, D3& 
     }
     // Lambertian (material.rs:77-117) / Isotropic (material.rs:278-300): sampled through a PDF
     const bool lambert = m.kind == RT_MAT_LAMBERTIAN;
-    D3 attenuation = texture_value(S, m.tex, h.u, h.v, h.p);
+    D3 attenuation = material_color(S, m, h.u, h.v, h.p);
     Onb uvw(h.normal); // CosinePdf::new (pdf.rs:46-48); unused for Isotropic
     D3 dir;
     bool from_light = false;

@@ -423,7 +423,8 @@ RT_DEV void set_face_normal(HitRec& h, D3 dir, D3 outward_normal) { // hittable.
     h.normal = h.front_face ? outward_normal : -outward_normal;
 }
 
-// want_uv = false skips the sphere's (u,v) (acos + atan2, sphere.rs:47-55) for callers that know nothing reads them.
+// want_uv = false skips the surface coordinates (sphere: acos + atan2, sphere.rs:47-55; quad and triangle: the fetch of
+// everything but normal and material) for callers that know nothing reads them.
 // `r` holds the world ray on entry (it is taken into the context of the hit here).
 RT_DEV void finalize(const DScene& S, RayD r, double time, const Best& b, HitRec& h, bool want_uv = true) {
     world_to_context(S, b.ctx, r);
@@ -447,20 +448,24 @@ RT_DEV void finalize(const DScene& S, RayD r, double time, const Best& b, HitRec
         h.mat = s.mat;
     } else if (kind == RT_REF_QUAD) { // quad.rs:95-108
         const DQuad* q = S.quads + idx;
-        D3 hp = h.p - d3p(q->q);
-        h.u = dot(d3p(q->w), cross(hp, d3p(q->v)));
-        h.v = dot(d3p(q->w), cross(d3p(q->u), hp));
+        if (want_uv) {
+            D3 hp = h.p - d3p(q->q);
+            h.u = dot(d3p(q->w), cross(hp, d3p(q->v)));
+            h.v = dot(d3p(q->w), cross(d3p(q->u), hp));
+        }
         set_face_normal(h, d, d3p(q->n));
         h.mat = q->mat;
     } else if (kind == RT_REF_TRI) { // triangle.rs:155-196
         const DTri* tp = S.tris + idx;
-        D3 v0 = d3p(tp->v0), v1 = d3p(tp->v1), v2 = d3p(tp->v2);
-        D3 edge1 = v1 - v0, edge2 = v2 - v0;
-        D3 hh = cross(d, edge2);
-        double f = 1.0 / dot(edge1, hh);
-        D3 s = o - v0;
-        h.u = f * dot(s, hh);
-        h.v = f * dot(d, cross(s, edge1));
+        if (want_uv) {
+            D3 v0 = d3p(tp->v0), v1 = d3p(tp->v1), v2 = d3p(tp->v2);
+            D3 edge1 = v1 - v0, edge2 = v2 - v0;
+            D3 hh = cross(d, edge2);
+            double f = 1.0 / dot(edge1, hh);
+            D3 s = o - v0;
+            h.u = f * dot(s, hh);
+            h.v = f * dot(d, cross(s, edge1));
+        }
         set_face_normal(h, d, d3p(tp->n));
         h.mat = tp->mat;
     } else { // constant medium (constant_medium.rs:96-101); u,v are not written by the reference
