@@ -114,8 +114,22 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, 
 
     bool active = false;
     bool pop = false;  // the lane has to take its next node or primitive from the stack
-    bool more = true;  // wave-uniform: the counter may still hold rays
-    unsigned long long wave_next = 0, wave_end = 0; // wave-uniform: the part of the batch this wave still owns
+    // Wave w starts on chunk w of the batch without asking anybody (at launch every wave would hit the counter
+    // at the same moment; a wave of an over-sized grid whose first chunk lies beyond the batch leaves at once).
+    // Later chunks: the waves of XCD x (workgroups are dealt round-robin over the 8 XCDs) take the chunks
+    // waves + 8k + x, k from a counter of their own, 128 bytes from the next one (fewer counters when the grid
+    // has fewer than 8 workgroups).
+    const unsigned long long waves_total = (unsigned long long)gridDim.x * FAST_WAVES;
+    const uint32_t work_slots = gridDim.x < 8u ? gridDim.x : 8u; // a small grid uses fewer counters: every residue class needs a taker
+    const uint32_t work_slot = blockIdx.x % work_slots;
+    unsigned long long* const my_counter = work_counter + work_slot * 16u;
+    // (the wave's index goes through readfirstlane so that the compiler keeps these in scalar registers)
+    const unsigned long long wave_index = (unsigned long long)blockIdx.x * FAST_WAVES + (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    unsigned long long wave_next = wave_index * (unsigned long long)chunk;                                                     // wave-uniform:
+    unsigned long long wave_end = wave_next + (unsigned long long)chunk;                                                        // the part of the batch this wave still owns
+    if (wave_end > n) wave_end = n;
+    bool more = wave_next < n; // wave-uniform: the batch may still hold rays for this wave
+    if (!more) wave_next = wave_end = n;
     RayD r;
     Ray32 q;
     float tmin32 = 0.0f, best32 = 0.0f;
@@ -135,16 +149,15 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, 
             const unsigned long long idle = __ballot(!active);
             if (idle) {
                 // The wave owns a private range [wave_next, wave_end) of the batch and takes a new one of
-                // `chunk` rays from the global counter only when it is used up: one device-wide atomic
-                // per chunk instead of one per refill (all waves increment the same word, and MI355X
-                // serves same-address atomics at roughly 10 ns each).
+                // `chunk` rays only when it is used up: one atomic per chunk instead of one per refill
+                // (MI355X serves same-address atomics at roughly 10 ns each).
                 if (wave_next >= wave_end) {
                     const int leader = __ffsll((long long)idle) - 1;
                     unsigned long long base = 0;
-                    if ((int)lane == leader) base = atomicAdd(work_counter, (unsigned long long)chunk);
+                    if ((int)lane == leader) base = atomicAdd(my_counter, 1ull);
                     const uint32_t blo = (uint32_t)__shfl((int)(uint32_t)base, leader);
                     const uint32_t bhi = (uint32_t)__shfl((int)(uint32_t)(base >> 32), leader);
-                    wave_next = ((unsigned long long)bhi << 32) | blo;
+                    wave_next = (waves_total + work_slot + (unsigned long long)work_slots * (((unsigned long long)bhi << 32) | blo)) * (unsigned long long)chunk;
                     wave_end = wave_next + (unsigned long long)chunk;
                     if (wave_end > n) wave_end = n;
                     if (wave_next >= n) { wave_next = wave_end = n; more = false; }

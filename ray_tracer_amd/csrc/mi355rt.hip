@@ -31,7 +31,8 @@ namespace {
 constexpr unsigned long long RANGES_PER_WAVE = 8ull; // work ranges a wave of a persistent kernel gets on average
 enum { C_WORK = 0, C_LIVE_IN = 1, C_LIVE_OUT = 2, C_NODES = 4, C_PRIMS = 5, C_RAYS = 6, C_WORDS = 32 };
 // Work counters of the general persistent kernels: one per XCD, each on a 128-byte line of its own, behind the
-// C_WORDS statistics words (the primitive-BVH kernel keeps its single counter C_WORK).
+// C_WORDS statistics words.
+// (The primitive-BVH kernel is handed the first slot and addresses them as work_counter + (workgroup % 8) * 16.)
 constexpr int WORK_SLOTS = 8, WORK_STRIDE = 16, C_WORK_SLOTS = 32, C_ALLOC = C_WORK_SLOTS + WORK_SLOTS * WORK_STRIDE;
 
 struct CamD { // Camera after initialize() (camera.rs:30-42)
@@ -102,7 +103,7 @@ __device__ __forceinline__ unsigned long long wave_fetch(unsigned long long* cou
 // was 8 % slower; so was looking at the counter with a plain load before paying for the last atomic).
 struct WaveWork {
     unsigned long long n, len, first_base, dynamic_base;
-    uint32_t slot;
+    uint32_t slot, slots;
     bool started;
     __device__ __forceinline__ WaveWork(unsigned long long n_) : n(n_), started(false) {
         const unsigned long long waves = (unsigned long long)gridDim.x * (blockDim.x / 64u);
@@ -110,7 +111,8 @@ struct WaveWork {
         const unsigned long long k = n / (waves * RANGES_PER_WAVE * 64ull);
         len = 64ull * (k < 1ull ? 1ull : (k > 16ull ? 16ull : k));
         first_base = wave_id * len;
-        slot = blockIdx.x % (uint32_t)WORK_SLOTS;
+        slots = gridDim.x < (uint32_t)WORK_SLOTS ? gridDim.x : (uint32_t)WORK_SLOTS; // every residue class needs a taker
+        slot = blockIdx.x % slots;
         dynamic_base = (waves + slot) * len;
     }
     // Next range [base, base + len) of this wave; base >= n when the batch is finished.  `counters` is the
@@ -118,7 +120,7 @@ struct WaveWork {
     __device__ __forceinline__ unsigned long long next(unsigned long long* counters) {
         if (!started) { started = true; return first_base; }
         if (dynamic_base >= n) return n;
-        return dynamic_base + wave_fetch(counters + C_WORK_SLOTS + slot * WORK_STRIDE, 1ull) * (unsigned long long)WORK_SLOTS * len;
+        return dynamic_base + wave_fetch(counters + C_WORK_SLOTS + slot * WORK_STRIDE, 1ull) * (unsigned long long)slots * len;
     }
 };
 
@@ -289,8 +291,19 @@ __global__ __launch_bounds__(BLOCK, 3) void extend_kernel(DScene S, PathState ps
             int32_t i = bg.x0 + (int32_t)(pix % (uint32_t)bg.tw);
             int32_t j = bg.y0 + (int32_t)(pix / (uint32_t)bg.tw);
             Rng g{seed, 0u, (uint32_t)(j * image_width + i), (uint32_t)(bg.sample0 + (int32_t)s_local), rec->rng_index};
+#ifdef RT_PHASE_STATS
+            s_lane_iters[threadIdx.x] = 0u;
+#endif
             traverse<MEDIA, false, true, true, !MEDIA>(S, S.world, r, 0, w, time, 0.001, b, stk, 0, &g, nn, np); // Interval::new(0.001, INFINITY) (camera.rs:258)
             RT_PHASE(2);
+#ifdef RT_PHASE_STATS
+            {
+                uint32_t it = s_lane_iters[threadIdx.x], mx = it, sm = it;
+                for (int o = 32; o > 0; o >>= 1) { uint32_t a = __shfl_xor(mx, o), c = __shfl_xor(sm, o); mx = a > mx ? a : mx; sm += c; }
+                const unsigned long long act = __popcll(__ballot(true));
+                if (lane == (uint32_t)__builtin_ctzll(__ballot(true))) { atomicAdd(&ps.counters[29], (unsigned long long)sm); atomicAdd(&ps.counters[30], (unsigned long long)mx * act); }
+            }
+#endif
             uint4 hit_block; // hit_t, hit_ref, hit_ctx
             hit_block.x = (uint32_t)__double2loint(b.t); hit_block.y = (uint32_t)__double2hiint(b.t);
             hit_block.z = b.ref; hit_block.w = (uint32_t)b.ctx;
@@ -619,7 +632,7 @@ int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit
         const uint32_t opt = (rays->time ? 1u : 0u) | (rays->tmin ? 2u : 0u) | (rays->tmax ? 4u : 0u);
         auto flaunch = [&](auto kernel) {
             hipLaunchKernelGGL(kernel, dim3(fblocks), dim3(FAST_BLOCK), 0, st, s->dev, s->flat.fast_root, *rays, (unsigned long long)n, rq, opt, 0.001,
-                               s->fast_extent, hits->t, hits->prim, s->d_counters + C_WORK, s->d_counters + C_NODES, s->fast_spill,
+                               s->fast_extent, hits->t, hits->prim, s->d_counters + C_WORK_SLOTS, s->d_counters + C_NODES, s->fast_spill,
                                env_int("MI355RT_REFILL", REFILL_THRESHOLD), env_int("MI355RT_VOTE", LEAF_VOTE), env_int("MI355RT_CHUNK", 0),
                                env_int("MI355RT_POP_TRIPS", POP_TRIPS));
         };
@@ -705,7 +718,7 @@ int render_impl(rt_scene* s, const rt_camera* cam, uint64_t seed, const rt_work*
                     uint32_t* out_prim = reinterpret_cast<uint32_t*>(ps.rec) + offsetof(PathRec, hit_ref) / sizeof(uint32_t);
                     int fblocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)s->fast_grid_blocks, (waves + (FAST_BLOCK / 64) - 1) / (FAST_BLOCK / 64)));
                     hipLaunchKernelGGL(fast_kernel_paths(s->fast_prim, s->fast_quant), dim3(fblocks), dim3(FAST_BLOCK), 0, st, s->dev, s->flat.fast_root,
-                                       view, (unsigned long long)live, rq, 1u, 0.001, s->fast_extent, out_t, out_prim, s->d_counters + C_WORK,
+                                       view, (unsigned long long)live, rq, 1u, 0.001, s->fast_extent, out_t, out_prim, s->d_counters + C_WORK_SLOTS,
                                        s->d_counters + C_NODES, s->fast_spill, env_int("MI355RT_REFILL", REFILL_THRESHOLD),
                                        env_int("MI355RT_VOTE", LEAF_VOTE), env_int("MI355RT_CHUNK", 0), env_int("MI355RT_POP_TRIPS", POP_TRIPS));
                 } else {
@@ -1001,6 +1014,7 @@ int rt_get_counters(rt_scene* s, rt_counters* out) {
 #ifdef RT_PHASE_STATS
             std::fprintf(stderr, "[mi355rt] shade wave cycles: record load %llu hit record %llu material %llu write-back %llu queue %llu\n", s->h_counters[24],
                          s->h_counters[25], s->h_counters[26], s->h_counters[27], s->h_counters[28]);
+            std::fprintf(stderr, "[mi355rt] traversal loop iterations: sum over lanes %llu, wave maximum x active lanes %llu\n", s->h_counters[29], s->h_counters[30]);
             std::fprintf(stderr, "[mi355rt] traversal step cycles: wide %llu exact %llu prim %llu list %llu xform %llu - %llu pop %llu\n", s->h_counters[8],
                          s->h_counters[9], s->h_counters[10], s->h_counters[11], s->h_counters[12], s->h_counters[13], s->h_counters[14]);
 #endif

@@ -154,6 +154,7 @@ RT_DEV void test_uniform_primitive(const DScene& S, uint32_t item, const RayD& r
 // wave cycles per kind of traversal step (stats build only): 0 wide/4-wide node, 1 exact node, 2 single primitive,
 // 3 list walk, 4 transform enter/leave, 5 medium bookkeeping, 6 pop
 __shared__ unsigned long long s_step_cycles[8];
+__shared__ uint32_t s_lane_iters[256]; // loop iterations of each lane's current traversal
 #define RT_STEP_BEGIN() const unsigned long long step_t0_ = __builtin_amdgcn_s_memtime()
 #define RT_STEP_END(k) do { if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) atomicAdd(&s_step_cycles[k], (unsigned long long)__builtin_amdgcn_s_memtime() - step_t0_); } while (0)
 #else
@@ -170,6 +171,9 @@ __device__ __forceinline__ void traverse(const DScene& S, uint32_t root, RayD ra
     const RayD entry_ray = ray;
     const int32_t entry_ctx = ctx;
     for (;;) {
+#ifdef RT_PHASE_STATS
+        if (TOP) s_lane_iters[threadIdx.x] += 1u;
+#endif
         const uint32_t kind = cur >> 28, idx = cur & 0x0FFFFFFFu;
         bool pop = true;
         bool wide_done = false;
