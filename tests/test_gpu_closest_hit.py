@@ -194,8 +194,8 @@ def test_degenerate_batches():
     s = rt.Scene(rt.HittableList.with_object(rt.Sphere(rt.Point3(0, 0, -1), 0.5, m)))
     h = s.closest_hit(np.zeros((0, 3)), np.zeros((0, 3)))
     assert len(h["t"]) == 0
-    # 1, 63, 64, 65 rays: ragged against the 64-lane chunking
-    for n in (1, 63, 64, 65, 257):
+    # ragged against the 64-lane chunking and against the per-wave work ranges of grids of 1..8 workgroups
+    for n in (1, 63, 64, 65, 257, 1500, 1793, 3000):
         o = np.zeros((n, 3))
         d = np.tile([0, 0, -1.0], (n, 1))
         d[::2] = [0, 0, 1.0]
