@@ -272,13 +272,15 @@ __global__ __launch_bounds__(BLOCK, 3) void extend_kernel(DScene S, PathState ps
         const unsigned long long base = work.next(ps.counters);
         RT_PHASE(0);
         if (base >= n) break;
+        uint32_t p_next = base + lane < n ? queue[base + lane] : 0u; // the queue entry is read one wave-load ahead of its record
         for (unsigned long long off = 0; off < chunk; off += 64ull) {
         unsigned long long q = base + off + lane;
 #ifdef RT_PHASE_STATS
         if (base + off < n) ++pieces;
 #endif
+        const uint32_t p = p_next;
+        if (off + 64ull < chunk && q + 64ull < n) p_next = queue[q + 64ull];
         if (q < n) {
-            uint32_t p = queue[q];
             PathRec* rec = ps.rec + p;
             const WorldRay w = path_ray(ps, p);
             RayD r;
@@ -348,12 +350,13 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(DScene S, CamD cam, PathSt
 #endif
     for (unsigned long long base = wave_id * chunk; base < n; base += waves * chunk) {
         uint32_t kept = 0; // wave-uniform
+        uint32_t p_next = base + lane < n ? qin[base + lane] : 0u; // the queue entry is read one wave-load ahead of its record
         for (unsigned long long off = 0; off < chunk; off += 64ull) {
             const unsigned long long q = base + off + lane;
             bool alive = false;
-            uint32_t p = 0;
+            const uint32_t p = p_next;
+            if (off + 64ull < chunk && q + 64ull < n) p_next = qin[q + 64ull];
             if (q < n) {
-                p = qin[q];
                 PathRec* rec = ps.rec + p;
                 D3 beta = d3p(rec->beta);
                 D3 L = d3p(rec->L);
