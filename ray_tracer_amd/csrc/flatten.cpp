@@ -237,7 +237,7 @@ struct Flattener {
                     const rt_texture& t = d->textures[m.tex];
                     o.albedo[0] = t.color[0]; o.albedo[1] = t.color[1]; o.albedo[2] = t.color[2];
                     o.tex = -1;
-                }
+                } else f.has_textures = true;
                 break;
             case RT_MAT_METAL: case RT_MAT_DIELECTRIC: break;
             default: return fail(RT_E_INVALID, "material: unknown kind");

@@ -43,6 +43,7 @@ struct FlatScene {
     double quant_inflation = 0.0;     // mean surface-area ratio of the 8-bit child boxes to their f32 boxes
     bool has_medium = false;
     bool uses_uv = false;             // an image texture exists: shading needs the spheres' (u,v)
+    bool has_textures = false;        // some material's texture is not a solid colour (checker, image, noise)
     Box world_bounds;
 };
 

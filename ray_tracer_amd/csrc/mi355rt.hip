@@ -327,6 +327,7 @@ __global__ __launch_bounds__(BLOCK, 3) void extend_kernel(DScene S, PathState ps
 }
 
 constexpr int SHADE_ROUNDS = 16; // wave-loads of paths whose survivors share one queue reservation
+template <bool TEXTURES>
 __global__ __launch_bounds__(BLOCK) void shade_kernel(DScene S, CamD cam, PathState ps, int qsel, unsigned long long seed, BatchGeom bg, int last_bounce) {
     const unsigned long long n = ps.counters[C_LIVE_IN];
     const uint32_t* qin = ps.queue[qsel];
@@ -371,22 +372,22 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(DScene S, CamD cam, PathSt
                     wr.dx = rec->d[0]; wr.dy = rec->d[1]; wr.dz = rec->d[2];
                     double time = rec->time;
                     HitRec h;
-                    finalize(S, wr, time, b, h, S.uses_uv != 0u); // only an image texture reads u,v (texture.rs:88-107)
+                    finalize(S, wr, time, b, h, TEXTURES && S.uses_uv != 0u); // only an image texture reads u,v (texture.rs:88-107)
                     RT_PHASE(1);
                     uint32_t s_local = p / bg.npix, pix = p - s_local * bg.npix;
                     int32_t i = bg.x0 + (int32_t)(pix % (uint32_t)bg.tw);
                     int32_t j = bg.y0 + (int32_t)(pix / (uint32_t)bg.tw);
                     Rng g{seed, 0u, (uint32_t)(j * cam.image_width + i), (uint32_t)(bg.sample0 + (int32_t)s_local), rec->rng_index};
                     D3 ray_dir = d3(wr.dx, wr.dy, wr.dz);
-                    D3 no, nd;
-                    alive = shade_hit(S, h, ray_dir, g, beta, L, no, nd);
+                    D3 nd;
+                    alive = shade_hit<TEXTURES>(S, h, ray_dir, g, beta, L, nd);
                     RT_PHASE(2);
                     if (alive) {
                         if (last_bounce) { // the next ray_color call has depth 0 and returns black (camera.rs:252-254)
                             L = L + beta * d3(0.0, 0.0, 0.0);
                             alive = false;
                         } else {
-                            rec->o[0] = no.x; rec->o[1] = no.y; rec->o[2] = no.z;
+                            rec->o[0] = h.p.x; rec->o[1] = h.p.y; rec->o[2] = h.p.z;
                             rec->d[0] = nd.x; rec->d[1] = nd.y; rec->d[2] = nd.z;
                             rec->beta[0] = beta.x; rec->beta[1] = beta.y; rec->beta[2] = beta.z;
                             rec->rng_index = g.index;
@@ -513,7 +514,8 @@ int pick_grid(rt_scene* s) {
     if (s->flat.has_medium) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, extend_kernel<true>, BLOCK, 0));
     else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, extend_kernel<false>, BLOCK, 0));
     int per_cu3 = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu3, shade_kernel, BLOCK, 0));
+    if (s->flat.has_textures) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu3, shade_kernel<true>, BLOCK, 0));
+    else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu3, shade_kernel<false>, BLOCK, 0));
     s->grid_blocks = prop.multiProcessorCount * std::max(1, per_cu);      // batched closest hit (general kernel)
     s->extend_blocks = prop.multiProcessorCount * std::max(1, per_cu2);   // each kernel fills the chip at its own occupancy
     s->shade_blocks = prop.multiProcessorCount * std::max(1, per_cu3);
@@ -728,7 +730,7 @@ int render_impl(rt_scene* s, const rt_camera* cam, uint64_t seed, const rt_work*
                     hipLaunchKernelGGL(s->flat.has_medium ? extend_kernel<true> : extend_kernel<false>, dim3(blocks), dim3(BLOCK), 0, st, s->dev, ps, qsel,
                                        (unsigned long long)seed, bg, cam->image_width);
                 }
-                hipLaunchKernelGGL(shade_kernel, dim3(sblocks), dim3(BLOCK), 0, st, s->dev, cd, ps, qsel, (unsigned long long)seed, bg, bounce == cam->max_depth - 1 ? 1 : 0);
+                hipLaunchKernelGGL((s->flat.has_textures || env_int("MI355RT_SHADE_TEXTURES", 0)) ? shade_kernel<true> : shade_kernel<false>, dim3(sblocks), dim3(BLOCK), 0, st, s->dev, cd, ps, qsel, (unsigned long long)seed, bg, bounce == cam->max_depth - 1 ? 1 : 0);
                 hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, st, s->d_counters);
                 s->counters.extend_launches += 1;
                 qsel ^= 1;

@@ -88,8 +88,12 @@ RT_DEV D3 texture_value(const DScene& S, int32_t tex, double u, double v, D3 p) 
     }
 }
 
+// TEXTURES = false: every texture of the scene is a solid colour (they all ride in the material records), and the
+// checker / image / noise code is compiled out.  That code alone costs the shading kernel about 100 vector
+// registers, i.e. one wave per SIMD.
+template <bool TEXTURES>
 RT_DEV D3 material_color(const DScene& S, const DMaterial& m, double u, double v, D3 p) {
-    if (m.tex < 0) return d3(m.albedo[0], m.albedo[1], m.albedo[2]);
+    if (!TEXTURES || m.tex < 0) return d3(m.albedo[0], m.albedo[1], m.albedo[2]);
     return texture_value(S, m.tex, u, v, p);
 }
 
@@ -175,18 +179,20 @@ RT_DEV D3 lights_random(const DScene& S, D3 origin, Rng& g) {
 }
 
 // ----------------------------------------------------------------- one bounce
-// Returns true when the path continues with (next_o, next_d); beta/L are updated in place.
-RT_DEV bool shade_hit(const DScene& S, const HitRec& h, D3 ray_dir, Rng& g, D3& beta, D3& L, D3& next_o, D3& next_d) {
+// Returns true when the path continues from the hit point h.p in direction next_d (every scattering material
+// starts the scattered ray at rec.p: material.rs:100, 153, 214, 291); beta/L are updated in place.
+template <bool TEXTURES>
+RT_DEV bool shade_hit(const DScene& S, const HitRec& h, D3 ray_dir, Rng& g, D3& beta, D3& L, D3& next_d) {
     const DMaterial m = S.materials[h.mat];
     if (m.kind == RT_MAT_DIFFUSE_LIGHT) { // material.rs:237-256: emits on the front face, never scatters
-        if (h.front_face) L = L + beta * material_color(S, m, h.u, h.v, h.p);
+        if (h.front_face) L = L + beta * material_color<TEXTURES>(S, m, h.u, h.v, h.p);
         return false;
     }
     if (m.kind == RT_MAT_METAL) { // material.rs:135-158; skip_pdf branch camera.rs:276-295
         D3 reflected = reflect(ray_dir, h.normal);
         reflected = unit_vector(reflected) + m.fuzz * random_unit_vector(g);
         beta = beta * d3(m.albedo[0], m.albedo[1], m.albedo[2]);
-        next_o = h.p; next_d = reflected;
+        next_d = reflected;
         return true;
     }
     if (m.kind == RT_MAT_DIELECTRIC) { // material.rs:181-217
@@ -206,12 +212,12 @@ RT_DEV bool shade_hit(const DScene& S, const HitRec& h, D3 ray_dir, Rng& g, D3& 
         }
         D3 direction = do_reflect ? reflect(unit_direction, h.normal) : refract(unit_direction, h.normal, ri);
         beta = beta * d3(1.0, 1.0, 1.0);
-        next_o = h.p; next_d = direction;
+        next_d = direction;
         return true;
     }
     // Lambertian (material.rs:77-117) / Isotropic (material.rs:278-300): sampled through a PDF
     const bool lambert = m.kind == RT_MAT_LAMBERTIAN;
-    D3 attenuation = material_color(S, m, h.u, h.v, h.p);
+    D3 attenuation = material_color<TEXTURES>(S, m, h.u, h.v, h.p);
     Onb uvw(h.normal); // CosinePdf::new (pdf.rs:46-48); unused for Isotropic
     D3 dir;
     bool from_light = false;
@@ -236,7 +242,7 @@ RT_DEV bool shade_hit(const DScene& S, const HitRec& h, D3 ray_dir, Rng& g, D3& 
         scattering_pdf = 1.0 / (4.0 * D_PI);
     }
     beta = (beta * (attenuation * scattering_pdf)) / pdf_value; // camera.rs:326-336
-    next_o = h.p; next_d = dir;
+    next_d = dir;
     return true;
 }
 

@@ -173,3 +173,23 @@ def test_render_device_entry_point_with_rank_units_on_a_stream():
                                 acc, c.image_width, d.image_height, d.sqrt_spp * d.sqrt_spp)
     torch.cuda.synchronize()
     assert np.allclose(acc.cpu().numpy(), full, rtol=1e-12, atol=1e-12, equal_nan=True)
+
+
+def test_shading_variants_agree_bit_for_bit(monkeypatch):
+    """Scenes whose textures are all solid colours are shaded by a kernel compiled without the texture code
+    (fewer registers, one more wave per SIMD).  MI355RT_SHADE_TEXTURES=1 forces the full kernel: two
+    independently compiled kernels must produce the same accumulator, bit for bit."""
+    cases = [scenes.cornell_box(image_width=120, samples_per_pixel=16, max_depth=50),
+             scenes.cornell_smoke(image_width=96, samples_per_pixel=9, max_depth=50),
+             scenes.mesh_and_spheres(image_width=96, samples_per_pixel=4, max_depth=20)]
+    w1, l1, c1 = scenes.book1_final(seed=2)  # metal, glass and diffuse spheres, defocus blur, no light list
+    c1.image_width, c1.samples_per_pixel, c1.max_depth = 120, 9, 30
+    cases.append((w1, l1, c1))
+    for world, lights, cam in cases:
+        g = rt.Scene(rt.SceneDesc.from_world(world, lights))
+        c = cam.to_struct()
+        monkeypatch.delenv("MI355RT_SHADE_TEXTURES", raising=False)
+        plain = g.render(c, seed=3).copy()
+        monkeypatch.setenv("MI355RT_SHADE_TEXTURES", "1")
+        full = g.render(c, seed=3).copy()
+        assert np.array_equal(plain, full, equal_nan=True)
