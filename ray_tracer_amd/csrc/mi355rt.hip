@@ -619,7 +619,11 @@ int ensure_workspace(rt_scene* s, uint64_t paths) {
 uint64_t max_paths_setting() {
     const char* e = getenv("MI355RT_MAX_PATHS");
     if (e) { long long v = atoll(e); if (v >= 1024) return (uint64_t)v; }
-    return 1ull << 26; // 8.6 GB of path records and queues: every bounce is a launch whose tail runs at one ray's latency, so few large batches beat many small ones (Cornell 600x600x100: 798 / 868 / 934 M samples/s at 2^24 / 2^25 / 2^26)
+    // 17 GB of path records and queues when a frame is that large (the workspace is sized to the frame, up to
+    // this cap): every bounce is a launch whose tail runs at one ray's latency, so few large batches beat many
+    // small ones.  Cornell 600x600x100: 798 / 868 / 934 M samples/s at 2^24 / 2^25 / 2^26; 625 spp: 1049 / 1088 /
+    // 1113 M at 2^26 / 2^27 / 2^28.
+    return 1ull << 27;
 }
 
 int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit_batch* hits, uint64_t seed, uint32_t flags, hipStream_t st) {
