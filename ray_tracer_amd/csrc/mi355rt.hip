@@ -339,7 +339,7 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(DScene S, CamD cam, PathSt
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long waves = (unsigned long long)gridDim.x * (blockDim.x / 64u);
     const unsigned long long wave_id = (unsigned long long)blockIdx.x * (blockDim.x / 64u) + (threadIdx.x >> 6);
-    unsigned long long rounds = n / (waves * 8ull * 64ull); // wave-loads per chunk: several chunks per wave, at most SHADE_ROUNDS
+    unsigned long long rounds = n / (waves * 2ull * 64ull); // wave-loads per chunk: at least two chunks per wave, at most SHADE_ROUNDS
     rounds = rounds < 1ull ? 1ull : (rounds > (unsigned long long)SHADE_ROUNDS ? (unsigned long long)SHADE_ROUNDS : rounds);
     const unsigned long long chunk = rounds * 64ull;
 #ifdef RT_PHASE_STATS
