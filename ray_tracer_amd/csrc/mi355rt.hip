@@ -28,6 +28,7 @@ using namespace rt;
 // ============================================================================ device code
 namespace {
 
+constexpr int TAIL_PATHS = 1 << 16; // a batch with this many live paths or fewer finishes in one launch (tail_kernel)
 constexpr unsigned long long RANGES_PER_WAVE = 8ull; // work ranges a wave of a persistent kernel gets on average
 enum { C_WORK = 0, C_LIVE_IN = 1, C_LIVE_OUT = 2, C_NODES = 4, C_PRIMS = 5, C_RAYS = 6, C_WORDS = 32 };
 // Work counters of the general persistent kernels: one per XCD, each on a 128-byte line of its own, behind the
@@ -417,6 +418,66 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(DScene S, CamD cam, PathSt
 #undef RT_PHASE
 }
 
+// The last bounces of a batch in one launch.  Once few paths are left, every bounce is a pair of launches that
+// last as long as their slowest wave (170-200 us per bounce in a BVH scene, for tens of bounces), with the chip
+// nearly empty.  Here a lane keeps its path and alternates traversal and shading until the path ends: the batch
+// then takes as long as its slowest path, not the sum over bounces of each bounce's slowest wave.  Same device
+// functions in the same order as extend_kernel + shade_kernel, so the same bits.
+template <bool MEDIA, bool TEXTURES>
+__global__ __launch_bounds__(BLOCK) void tail_kernel(DScene S, CamD cam, PathState ps, int qsel, unsigned long long seed, BatchGeom bg,
+                                                     int first_bounce, int max_depth) {
+    __shared__ uint32_t s_stack[STACK_MAX * BLOCK];
+    uint32_t* stk = s_stack + threadIdx.x;
+    const unsigned long long n = ps.counters[C_LIVE_IN];
+    const uint32_t* queue = ps.queue[qsel];
+    const unsigned long long threads = (unsigned long long)gridDim.x * blockDim.x;
+    unsigned long long traced = 0;
+    uint32_t nn = 0, np = 0;
+    for (unsigned long long q = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += threads) {
+        const uint32_t p = queue[q];
+        PathRec* rec = ps.rec + p;
+        const WorldRay w = path_ray(ps, p); // reads rec->o / rec->d: they are kept current in memory below
+        RayD r;
+        r.ox = rec->o[0]; r.oy = rec->o[1]; r.oz = rec->o[2];
+        r.dx = rec->d[0]; r.dy = rec->d[1]; r.dz = rec->d[2];
+        const double time = rec->time;
+        D3 beta = d3p(rec->beta);
+        D3 L = d3p(rec->L);
+        uint32_t s_local = p / bg.npix, pix = p - s_local * bg.npix;
+        int32_t i = bg.x0 + (int32_t)(pix % (uint32_t)bg.tw);
+        int32_t j = bg.y0 + (int32_t)(pix / (uint32_t)bg.tw);
+        Rng g{seed, 0u, (uint32_t)(j * cam.image_width + i), (uint32_t)(bg.sample0 + (int32_t)s_local), rec->rng_index};
+        for (int bounce = first_bounce; bounce < max_depth; ++bounce) {
+            set_inverse(r);
+            Best b;
+            b.t = D_INF; b.ref = RT_REF_NONE; b.ctx = 0;
+            traverse<MEDIA, false, true, true, false>(S, S.world, r, 0, w, time, 0.001, b, stk, 0, &g, nn, np); // Interval::new(0.001, INFINITY) (camera.rs:258)
+            ++traced;
+            if (b.ref == RT_REF_NONE) { // camera.rs:258-260
+                L = L + beta * d3p(cam.background);
+                break;
+            }
+            HitRec h;
+            finalize(S, r, time, b, h, TEXTURES && S.uses_uv != 0u);
+            D3 ray_dir = d3(r.dx, r.dy, r.dz);
+            D3 nd;
+            if (!shade_hit<TEXTURES>(S, h, ray_dir, g, beta, L, nd)) break;
+            if (bounce == max_depth - 1) { // the next ray_color call has depth 0 and returns black (camera.rs:252-254)
+                L = L + beta * d3(0.0, 0.0, 0.0);
+                break;
+            }
+            r.ox = h.p.x; r.oy = h.p.y; r.oz = h.p.z;
+            r.dx = nd.x; r.dy = nd.y; r.dz = nd.z;
+            rec->o[0] = h.p.x; rec->o[1] = h.p.y; rec->o[2] = h.p.z;
+            rec->d[0] = nd.x; rec->d[1] = nd.y; rec->d[2] = nd.z;
+        }
+        rec->L[0] = L.x; rec->L[1] = L.y; rec->L[2] = L.z;
+    }
+    // extend queries of this launch, for the counter the separate launches keep in advance_kernel
+    for (int o = 32; o > 0; o >>= 1) traced += (unsigned long long)__shfl_xor((long long)traced, o);
+    if ((threadIdx.x & 63u) == 0u && traced) atomicAdd(&ps.counters[C_RAYS], traced);
+}
+
 __global__ __launch_bounds__(BLOCK) void accumulate_kernel(PathState ps, BatchGeom bg, double* accum, int32_t image_width) {
     uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
     if (pix >= bg.npix) return;
@@ -449,7 +510,7 @@ struct rt_scene {
     rt_counters counters{};
     int grid_blocks = 0;
     int fast_grid_blocks = 0;
-    int extend_blocks = 0, shade_blocks = 0;
+    int extend_blocks = 0, shade_blocks = 0, tail_blocks = 0;
     size_t fast_lds = 0;
     uint2* fast_spill = nullptr; // HBM overflow of the per-lane stacks: [entry][thread]
     int fast_prim = 0;           // leaf kind of the primitive BVH when uniform, else 0
@@ -519,6 +580,10 @@ int pick_grid(rt_scene* s) {
     s->grid_blocks = prop.multiProcessorCount * std::max(1, per_cu);      // batched closest hit (general kernel)
     s->extend_blocks = prop.multiProcessorCount * std::max(1, per_cu2);   // each kernel fills the chip at its own occupancy
     s->shade_blocks = prop.multiProcessorCount * std::max(1, per_cu3);
+    int per_cu4 = 0;
+    if (s->flat.has_medium) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu4, tail_kernel<true, true>, BLOCK, 0));
+    else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu4, tail_kernel<false, true>, BLOCK, 0));
+    s->tail_blocks = prop.multiProcessorCount * std::max(1, per_cu4);
     if (s->flat.fast_root != RT_REF_NONE) {
         s->fast_lds = 0;
         s->fast_extent = s->flat.q_extent;
@@ -711,7 +776,20 @@ int render_impl(rt_scene* s, const rt_camera* cam, uint64_t seed, const rt_work*
             uint64_t live = bg.npaths;
             // MI355RT_FAST_EXTEND=0 keeps the general traversal for BVH-only worlds (A/B measurements)
             const bool fast_extend = s->flat.fast_root != RT_REF_NONE && env_int("MI355RT_FAST_EXTEND", 1) != 0;
+            const bool has_tex = s->flat.has_textures || env_int("MI355RT_SHADE_TEXTURES", 0); // the switch forces the full shading code (A/B tests)
+            const uint64_t tail_paths = (uint64_t)env_int("MI355RT_TAIL_PATHS", TAIL_PATHS);
+            bool live_exact = true; // `live` is the device's count (it is refreshed only now and then)
             for (int32_t bounce = 0; bounce < cam->max_depth && live > 0; ++bounce) {
+                if (live_exact && bounce > 0 && live <= tail_paths) {
+                    // few paths left: they finish in one launch, each lane following its path to the end
+                    const int tblocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)s->tail_blocks, (live + BLOCK - 1) / BLOCK));
+                    auto tail = s->flat.has_medium ? (has_tex ? tail_kernel<true, true> : tail_kernel<true, false>)
+                                                   : (has_tex ? tail_kernel<false, true> : tail_kernel<false, false>);
+                    hipLaunchKernelGGL(tail, dim3(tblocks), dim3(BLOCK), 0, st, s->dev, cd, ps, qsel, (unsigned long long)seed, bg, (int)bounce, (int)cam->max_depth);
+                    s->counters.extend_launches += 1;
+                    break;
+                }
+                live_exact = false;
                 uint64_t waves = (live + 63) / 64;
                 const uint64_t want = (waves + (BLOCK / 64) - 1) / (BLOCK / 64);
                 const int blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)s->extend_blocks, want));
@@ -734,17 +812,19 @@ int render_impl(rt_scene* s, const rt_camera* cam, uint64_t seed, const rt_work*
                     hipLaunchKernelGGL(s->flat.has_medium ? extend_kernel<true> : extend_kernel<false>, dim3(blocks), dim3(BLOCK), 0, st, s->dev, ps, qsel,
                                        (unsigned long long)seed, bg, cam->image_width);
                 }
-                hipLaunchKernelGGL((s->flat.has_textures || env_int("MI355RT_SHADE_TEXTURES", 0)) ? shade_kernel<true> : shade_kernel<false>, dim3(sblocks), dim3(BLOCK), 0, st, s->dev, cd, ps, qsel, (unsigned long long)seed, bg, bounce == cam->max_depth - 1 ? 1 : 0);
+                hipLaunchKernelGGL(has_tex ? shade_kernel<true> : shade_kernel<false>, dim3(sblocks), dim3(BLOCK), 0, st, s->dev, cd, ps, qsel, (unsigned long long)seed, bg, bounce == cam->max_depth - 1 ? 1 : 0);
                 hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, st, s->d_counters);
                 s->counters.extend_launches += 1;
                 qsel ^= 1;
                 // `live` only sizes the next launches and ends a dead batch early (the kernels read the exact count
                 // on the device).  Each refresh is a host round trip with the GPU idle, which costs more than a few
-                // over-sized launches, so it happens at bounces 2, 5, 9, then every 8th.
-                if (bounce == 2 || bounce == 5 || bounce == 9 || (bounce > 9 && (bounce & 7) == 1)) {
+                // over-sized launches, so it happens at bounces 2, 5, 9, then every 3rd (by then the batch is close to the
+                // size at which tail_kernel takes over, and the refresh is what lets it).
+                if (bounce == 2 || bounce == 5 || bounce == 9 || (bounce > 9 && bounce % 3 == 0)) {
                     HIP_TRY(hipMemcpyAsync(s->h_counters, s->d_counters, C_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
                     HIP_TRY(hipStreamSynchronize(st));
                     live = s->h_counters[C_LIVE_IN];
+                    live_exact = true;
                 }
             }
             hipLaunchKernelGGL(accumulate_kernel, dim3((bg.npix + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, ps, bg, d_accum, cam->image_width);

@@ -193,3 +193,24 @@ def test_shading_variants_agree_bit_for_bit(monkeypatch):
         monkeypatch.setenv("MI355RT_SHADE_TEXTURES", "1")
         full = g.render(c, seed=3).copy()
         assert np.array_equal(plain, full, equal_nan=True)
+
+
+def test_tail_kernel_agrees_bit_for_bit(monkeypatch):
+    """The last bounces of a batch run in one launch in which every lane follows its path to the end
+    (MI355RT_TAIL_PATHS: the live-path count at which it takes over; 0 = never).  Whatever the switch-over
+    point, the accumulator must be the same, bit for bit, and the extend-query count too."""
+    cases = [scenes.cornell_box(image_width=96, samples_per_pixel=16, max_depth=50),
+             scenes.cornell_smoke(image_width=64, samples_per_pixel=9, max_depth=50),
+             scenes.book2_final(seed=0, image_width=64, samples_per_pixel=4, max_depth=40),
+             scenes.mesh_and_spheres(image_width=96, samples_per_pixel=4, max_depth=20)]
+    for world, lights, cam in cases:
+        g = rt.Scene(rt.SceneDesc.from_world(world, lights))
+        c = cam.to_struct()
+        out = {}
+        for tail in ("0", "1000", "1073741824"):  # never / late / from the second bounce on
+            monkeypatch.setenv("MI355RT_TAIL_PATHS", tail)
+            g.reset_counters()
+            out[tail] = (g.render(c, seed=5).copy(), g.counters().render_rays)
+        for tail in ("1000", "1073741824"):
+            assert np.array_equal(out["0"][0], out[tail][0], equal_nan=True), tail
+            assert out["0"][1] == out[tail][1], tail
