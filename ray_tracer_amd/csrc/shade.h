@@ -135,8 +135,19 @@ RT_DEV double lights_pdf_value(const DScene& S, D3 origin, D3 direction) {
     return sum;
 }
 
-// random() of one light (quad.rs:133-136; sphere.rs:133-141, 57-67): two draws either way.
-RT_DEV D3 light_random_one(const DScene& S, DLight l, D3 origin, Rng& g) { // `l` is wave-uniform
+// Direction sampling of the mixture PDF (pdf.rs:119-125).  Two of the samplers have the same shape: the cosine
+// lobe about the normal (pdf.rs:57-59) and the cone towards a sphere light (sphere.rs:57-67, 133-141) both build
+// an orthonormal basis about an axis, draw two numbers, and place a point at azimuth 2*pi*r1.  Lanes of either kind
+// run that part together (`SAMPLE_LOBE`), each with its own axis and its own two radial expressions; a quad light
+// (quad.rs:133-136) or a list member without a sampler (hittable.rs:54-56) yields its direction at once.
+enum { SAMPLE_DONE = 0, SAMPLE_LOBE = 1 };
+struct LobeSample {
+    D3 axis;       // the normal, or the direction to the sphere's centre
+    double cone;   // sphere light: sqrt(1 - r^2 / distance^2) - 1; unused for the cosine lobe
+    bool sphere;
+};
+
+RT_DEV int light_pick_one(const DScene& S, DLight l, D3 origin, Rng& g, D3& dir, LobeSample& lobe) { // `l` is wave-uniform
     if (l.kind == RT_REF_QUAD) {
         const DQuad q = uniform_load(S.quads + l.index);
         double r1 = g.next();
@@ -144,38 +155,51 @@ RT_DEV D3 light_random_one(const DScene& S, DLight l, D3 origin, Rng& g) { // `l
         double r2 = g.next();
         D3 b = r2 * d3p(q.v);
         D3 p = d3p(q.q) + a + b;
-        return p - origin;
+        dir = p - origin;
+        return SAMPLE_DONE;
     }
     if (l.kind == RT_REF_SPHERE) {
         const DSphere s = uniform_load(S.spheres + l.index);
         D3 center = d3(s.c[0], s.c[1], s.c[2]) + 0.0 * d3(s.dc[0], s.dc[1], s.dc[2]);
         D3 direction = center - origin;
         double distance_squared = length_squared(direction);
-        Onb uvw(direction);
-        double r1 = g.next();
-        double r2 = g.next();
-        double z = 1.0 + r2 * (sqrt(1.0 - s.radius * s.radius / distance_squared) - 1.0);
-        double sphi, cphi;
-        sincos_2pi(r1, sphi, cphi);
-        double x = cphi * sqrt(1.0 - z * z);
-        double y = sphi * sqrt(1.0 - z * z);
-        return uvw.transform(d3(x, y, z));
+        lobe.axis = direction;
+        lobe.cone = sqrt(1.0 - s.radius * s.radius / distance_squared) - 1.0;
+        lobe.sphere = true;
+        return SAMPLE_LOBE;
     }
-    return d3(1.0, 0.0, 0.0); // hittable.rs:54-56
+    dir = d3(1.0, 0.0, 0.0); // hittable.rs:54-56
+    return SAMPLE_DONE;
 }
 
-RT_DEV D3 lights_random(const DScene& S, D3 origin, Rng& g) {
-    if (!S.lights_is_list) return light_random_one(S, uniform_load(S.lights), origin, g);
+RT_DEV int lights_pick(const DScene& S, D3 origin, Rng& g, D3& dir, LobeSample& lobe) {
+    if (!S.lights_is_list) return light_pick_one(S, uniform_load(S.lights), origin, g, dir, lobe);
     const int32_t index = g.random_int(0, S.n_lights - 1); // hittable_list.rs:78-81
-    D3 out = d3(1.0, 0.0, 0.0);
+    int mode = SAMPLE_DONE;
+    dir = d3(1.0, 0.0, 0.0);
     // every lane picked its own light; the lights are visited one after the other (what the hardware does with a
     // divergent branch anyway), each as a wave-uniform record
     for (int32_t i = 0; i < S.n_lights; ++i) {
         if (__builtin_amdgcn_ballot_w64(index == i) == 0ull) continue;
         const DLight l = uniform_load(S.lights + i);
-        if (index == i) out = light_random_one(S, l, origin, g);
+        if (index == i) mode = light_pick_one(S, l, origin, g, dir, lobe);
     }
-    return out;
+    return mode;
+}
+
+RT_DEV D3 sample_lobe(const LobeSample& lobe, Rng& g) {
+    Onb uvw(lobe.axis);
+    double r1 = g.next();
+    double r2 = g.next();
+    double sphi, cphi;
+    sincos_2pi(r1, sphi, cphi);
+    // sphere.rs:62-66: z = 1 + r2*(sqrt(1 - r^2/d^2) - 1), x = cos(phi)*sqrt(1 - z*z); pdf.rs / vec3 random_cosine_direction:
+    // z = sqrt(1 - r2), x = cos(phi)*sqrt(r2)
+    double z = lobe.sphere ? 1.0 + r2 * lobe.cone : sqrt(1.0 - r2);
+    double radial = lobe.sphere ? sqrt(1.0 - z * z) : sqrt(r2);
+    double x = cphi * radial;
+    double y = sphi * radial;
+    return uvw.transform(d3(x, y, z));
 }
 
 // ----------------------------------------------------------------- one bounce
@@ -218,16 +242,20 @@ RT_DEV bool shade_hit(const DScene& S, const HitRec& h, D3 ray_dir, Rng& g, D3& 
     // Lambertian (material.rs:77-117) / Isotropic (material.rs:278-300): sampled through a PDF
     const bool lambert = m.kind == RT_MAT_LAMBERTIAN;
     D3 attenuation = material_color<TEXTURES>(S, m, h.u, h.v, h.p);
-    Onb uvw(h.normal); // CosinePdf::new (pdf.rs:46-48); unused for Isotropic
-    D3 dir;
+    const D3 unit_normal = unit_vector(h.normal); // the w axis of CosinePdf's basis (pdf.rs:46-48, onb.rs:13); unused for Isotropic
+    D3 dir = d3(1.0, 0.0, 0.0);
     bool from_light = false;
     if (S.n_lights >= 0) from_light = g.next() < 0.5; // MixturePdf::generate (pdf.rs:119-125)
-    if (from_light) dir = lights_random(S, h.p, g);
-    else if (lambert) dir = uvw.transform(random_cosine_direction(g)); // pdf.rs:57-59
+    int mode = SAMPLE_DONE;
+    LobeSample lobe;
+    lobe.axis = h.normal; lobe.cone = 0.0; lobe.sphere = false;
+    if (from_light) mode = lights_pick(S, h.p, g, dir, lobe);
+    else if (lambert) mode = SAMPLE_LOBE;                              // pdf.rs:57-59
     else dir = random_unit_vector(g);                                  // pdf.rs:36-38
+    if (mode == SAMPLE_LOBE) dir = sample_lobe(lobe, g);
     double mat_pdf;
     if (lambert) { // CosinePdf::value (pdf.rs:52-55)
-        double cosine_theta = dot(unit_vector(dir), uvw.a2);
+        double cosine_theta = dot(unit_vector(dir), unit_normal);
         mat_pdf = fmax(cosine_theta / D_PI, 0.0);
     } else {
         mat_pdf = 1.0 / (4.0 * D_PI);
