@@ -268,6 +268,33 @@ def test_wide_nodes_fall_back_to_f32_when_one_primitive_dwarfs_the_rest():
     assert len(rt.Scene(rt.SceneDesc.from_world(world, lights), host_only=True).wide_nodes()) == 0
 
 
+def test_wide_nodes_report_boxes_as_their_lists():
+    """A box is a list of six consecutive quads; inside the 4-wide nodes it is entered through a reference that
+    names the quads directly, and the introspection call reports the list it stands for."""
+    rng = np.random.default_rng(3)
+    m = rt.Lambertian(rt.Color(.5, .5, .5))
+    boxes = rt.HittableList()
+    corners = []
+    for _ in range(50):
+        a = rng.uniform(0.0, 10.0, 3)
+        b = a + rng.uniform(0.2, 1.0, 3)
+        corners.append((a, b))
+        boxes.add(rt.box_new(rt.Point3(*a), rt.Point3(*b), m))
+    desc = rt.SceneDesc.from_world(rt.HittableList.with_object(rt.BvhNode(boxes)))
+    sc = rt.Scene(desc, host_only=True)
+    wn = sc.wide_nodes()
+    assert len(wn) > 10
+    leaves = [int(r) for r in wn["child"].reshape(-1) if r != F.RT_REF_NONE and (int(r) >> 28) != F.RT_REF_NODE]
+    assert len(leaves) == 50 and len(set(leaves)) == 50
+    assert all((r >> 28) == F.RT_REF_LIST for r in leaves)
+    # the root's child boxes together cover every box of the scene
+    root = wn[0]
+    valid = root["child"] != F.RT_REF_NONE
+    lo = root["box32"][valid][:, 0::2].min(axis=0)
+    hi = root["box32"][valid][:, 1::2].max(axis=0)
+    assert np.all(lo <= np.min([c[0] for c in corners], axis=0)) and np.all(hi >= np.max([c[1] for c in corners], axis=0))
+
+
 def test_reference_side_binding_in_integration_md_covers_the_header():
     """The Rust `extern "C"` block a maintainer of the reference would add (it cannot be compiled here: no Rust
     toolchain) must name every function of the header, and its #[repr(C)] structs must list the fields of the
