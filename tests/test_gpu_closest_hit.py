@@ -125,6 +125,28 @@ def test_cornell_box_instances_and_ties():
     compare(desc, src, tgt - src, min_hits=3000)
 
 
+def test_bvh_of_boxes_quad_runs():
+    """A BVH whose leaves are boxes (lists of six consecutive quads): the ordered traversal enters them without
+    reading the list, per lane for incoherent rays and through the scalar path when a whole wave stands at the
+    same box (identical rays)."""
+    m = rt.Lambertian(rt.Color(.5, .5, .5))
+    boxes = rt.HittableList()
+    g = np.random.default_rng(21)
+    for ix in range(8):
+        for iz in range(8):
+            h = float(g.uniform(0.2, 2.0))
+            boxes.add(rt.box_new(rt.Point3(ix, 0.0, iz), rt.Point3(ix + 0.9, h, iz + 0.9), m))
+    world = rt.HittableList.with_object(rt.BvhNode(boxes))
+    world.add(rt.Sphere(rt.Point3(4.0, 4.0, 4.0), 1.0, m))
+    desc = rt.SceneDesc.from_world(world)
+    o, d, tm = scenes.incoherent_rays(40000, [0, 8, 0, 5, 0, 8], seed=22)
+    for flags in (0, F.RT_HIT_ORDERED):
+        compare(desc, o, d, time=tm, min_hits=15000, flags=flags)
+        oo = np.tile([[4.3, 6.0, 3.7]], (4096, 1))          # every lane of every wave traces the same ray
+        dd = np.tile([[0.1, -1.0, 0.05]], (4096, 1))
+        compare(desc, oo, dd, min_hits=4096, flags=flags)
+
+
 def test_book2_scene_with_media():
     world, lights, cam = scenes.book2_final(seed=0)
     desc = rt.SceneDesc.from_world(world, lights)
