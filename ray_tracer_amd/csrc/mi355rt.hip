@@ -778,6 +778,8 @@ int render_impl(rt_scene* s, const rt_camera* cam, uint64_t seed, const rt_work*
             const bool fast_extend = s->flat.fast_root != RT_REF_NONE && env_int("MI355RT_FAST_EXTEND", 1) != 0;
             const bool has_tex = s->flat.has_textures || env_int("MI355RT_SHADE_TEXTURES", 0); // the switch forces the full shading code (A/B tests)
             const uint64_t tail_paths = (uint64_t)env_int("MI355RT_TAIL_PATHS", TAIL_PATHS);
+            const int k_refill = env_int("MI355RT_REFILL", REFILL_THRESHOLD), k_vote = env_int("MI355RT_VOTE", LEAF_VOTE); // read once per batch,
+            const int k_chunk = env_int("MI355RT_CHUNK", 0), k_pop = env_int("MI355RT_POP_TRIPS", POP_TRIPS);                // not once per bounce
             bool live_exact = true; // `live` is the device's count (it is refreshed only now and then)
             for (int32_t bounce = 0; bounce < cam->max_depth && live > 0; ++bounce) {
                 if (live_exact && bounce > 0 && live <= tail_paths) {
@@ -806,8 +808,7 @@ int render_impl(rt_scene* s, const rt_camera* cam, uint64_t seed, const rt_work*
                     int fblocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)s->fast_grid_blocks, (waves + (FAST_BLOCK / 64) - 1) / (FAST_BLOCK / 64)));
                     hipLaunchKernelGGL(fast_kernel_paths(s->fast_prim, s->fast_quant), dim3(fblocks), dim3(FAST_BLOCK), 0, st, s->dev, s->flat.fast_root,
                                        view, (unsigned long long)live, rq, 1u, 0.001, s->fast_extent, out_t, out_prim, s->d_counters + C_WORK_SLOTS,
-                                       s->d_counters + C_NODES, s->fast_spill, env_int("MI355RT_REFILL", REFILL_THRESHOLD),
-                                       env_int("MI355RT_VOTE", LEAF_VOTE), env_int("MI355RT_CHUNK", 0), env_int("MI355RT_POP_TRIPS", POP_TRIPS));
+                                       s->d_counters + C_NODES, s->fast_spill, k_refill, k_vote, k_chunk, k_pop);
                 } else {
                     hipLaunchKernelGGL(s->flat.has_medium ? extend_kernel<true> : extend_kernel<false>, dim3(blocks), dim3(BLOCK), 0, st, s->dev, ps, qsel,
                                        (unsigned long long)seed, bg, cam->image_width);
