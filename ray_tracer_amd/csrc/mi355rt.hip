@@ -328,6 +328,7 @@ __global__ __launch_bounds__(BLOCK, 3) void extend_kernel(DScene S, PathState ps
 }
 
 constexpr int SHADE_ROUNDS = 16; // wave-loads of paths whose survivors share one queue reservation
+constexpr unsigned long long SHADE_GROUP = 4ull; // consecutive wave-loads a wave shades before it moves on by a stride of all waves
 template <bool TEXTURES>
 __global__ __launch_bounds__(BLOCK) void shade_kernel(DScene S, CamD cam, PathState ps, int qsel, unsigned long long seed, BatchGeom bg, int last_bounce) {
     const unsigned long long n = ps.counters[C_LIVE_IN];
@@ -340,9 +341,14 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(DScene S, CamD cam, PathSt
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long waves = (unsigned long long)gridDim.x * (blockDim.x / 64u);
     const unsigned long long wave_id = (unsigned long long)blockIdx.x * (blockDim.x / 64u) + (threadIdx.x >> 6);
-    unsigned long long rounds = n / (waves * 2ull * 64ull); // wave-loads per chunk: at least two chunks per wave, at most SHADE_ROUNDS
-    rounds = rounds < 1ull ? 1ull : (rounds > (unsigned long long)SHADE_ROUNDS ? (unsigned long long)SHADE_ROUNDS : rounds);
-    const unsigned long long chunk = rounds * 64ull;
+    // Wave w shades groups of SHADE_GROUP consecutive wave-loads, w, w + waves, w + 2*waves, ... in units of
+    // groups: no wave gets more than one group above its share (handing out whole chunks of 16 wave-loads left a
+    // quarter of the waves with 4 chunks and the rest with 3 at 12 M paths), at any moment the chip works on one
+    // window of the queue, and neighbours in the queue stay neighbours in the next one (single wave-loads
+    // interleaved across waves balance better still but cost the BVH scenes 3 %: the next bounce's waves
+    // then mix paths from distant parts of the frame).
+    const unsigned long long loads = (n + 63ull) / 64ull;
+    const unsigned long long groups = (loads + SHADE_GROUP - 1ull) / SHADE_GROUP;
 #ifdef RT_PHASE_STATS
     unsigned long long ph[5] = {0ull, 0ull, 0ull, 0ull, 0ull}; // wave cycles: record load, hit record, material, write-back, queue
 #define RT_PHASE(k) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ph[k] += now_ - t_ph; t_ph = now_; } while (0)
@@ -350,14 +356,18 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(DScene S, CamD cam, PathSt
 #else
 #define RT_PHASE(k) do { } while (0)
 #endif
-    for (unsigned long long base = wave_id * chunk; base < n; base += waves * chunk) {
-        uint32_t kept = 0; // wave-uniform
-        uint32_t p_next = base + lane < n ? qin[base + lane] : 0u; // the queue entry is read one wave-load ahead of its record
-        for (unsigned long long off = 0; off < chunk; off += 64ull) {
-            const unsigned long long q = base + off + lane;
+    {
+        uint32_t kept = 0, rounds = 0; // wave-uniform
+        uint32_t p_next = wave_id * SHADE_GROUP * 64ull + lane < n ? qin[wave_id * SHADE_GROUP * 64ull + lane] : 0u; // the queue entry is read one wave-load ahead of its record
+        for (unsigned long long grp = wave_id; grp < groups; grp += waves)
+        for (unsigned long long load = grp * SHADE_GROUP; load < (grp + 1ull) * SHADE_GROUP && load < loads; ++load) {
+            const unsigned long long q = load * 64ull + lane;
             bool alive = false;
             const uint32_t p = p_next;
-            if (off + 64ull < chunk && q + 64ull < n) p_next = qin[q + 64ull];
+            {
+                const unsigned long long q_next = load + 1ull < (grp + 1ull) * SHADE_GROUP ? q + 64ull : ((grp + waves) * SHADE_GROUP) * 64ull + lane;
+                if (q_next < n) p_next = qin[q_next];
+            }
             if (q < n) {
                 PathRec* rec = ps.rec + p;
                 D3 beta = d3p(rec->beta);
@@ -401,16 +411,21 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(DScene S, CamD cam, PathSt
             const unsigned long long mask = __ballot(alive);
             if (alive) keep[kept + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = p;
             kept += (uint32_t)__popcll(mask);
+            ++rounds;
+            const bool last_of_wave = grp + waves >= groups && (load + 1ull == (grp + 1ull) * SHADE_GROUP || load + 1ull == loads);
+            if ((rounds == (uint32_t)SHADE_ROUNDS || last_of_wave) && kept) {
+                // the survivors collected so far take consecutive slots of the next queue
+                unsigned long long slot = 0;
+                if (lane == 0u) slot = atomicAdd(&ps.counters[C_LIVE_OUT], (unsigned long long)kept);
+                const uint32_t slot_lo = __builtin_amdgcn_readfirstlane((uint32_t)slot);
+                __builtin_amdgcn_wave_barrier();
+                for (uint32_t k = lane; k < kept; k += 64u) qout[slot_lo + k] = keep[k];
+                __builtin_amdgcn_wave_barrier();
+                kept = 0;
+            }
+            if (rounds == (uint32_t)SHADE_ROUNDS) rounds = 0;
+            RT_PHASE(4);
         }
-        if (kept) { // surviving paths of this chunk take consecutive slots of the next queue
-            unsigned long long slot = 0;
-            if (lane == 0u) slot = atomicAdd(&ps.counters[C_LIVE_OUT], (unsigned long long)kept);
-            const uint32_t slot_lo = __builtin_amdgcn_readfirstlane((uint32_t)slot);
-            __builtin_amdgcn_wave_barrier();
-            for (uint32_t k = lane; k < kept; k += 64u) qout[slot_lo + k] = keep[k];
-            __builtin_amdgcn_wave_barrier();
-        }
-        RT_PHASE(4);
     }
 #ifdef RT_PHASE_STATS
     if (lane == 0u) for (int k = 0; k < 5; ++k) atomicAdd(&ps.counters[24 + k], ph[k]);
