@@ -102,26 +102,35 @@ __device__ __forceinline__ unsigned long long wave_fetch(unsigned long long* cou
 // order, so at any moment the whole chip works on one window of the queue, which keeps the path records it
 // gathers close together in HBM (an even static split, every wave streaming through a region of its own,
 // was 8 % slower; so was looking at the counter with a plain load before paying for the last atomic).
+// The last quarter of the batch is handed out in ranges a quarter as long: a launch ends when its last range
+// does, and with ~8 ranges per wave a full-length last range is an eighth of the launch.
 struct WaveWork {
-    unsigned long long n, len, first_base, dynamic_base;
+    unsigned long long n, len, short_len, n_long, waves, wave_id;
     uint32_t slot, slots;
     bool started;
     __device__ __forceinline__ WaveWork(unsigned long long n_) : n(n_), started(false) {
-        const unsigned long long waves = (unsigned long long)gridDim.x * (blockDim.x / 64u);
-        const unsigned long long wave_id = (unsigned long long)blockIdx.x * (blockDim.x / 64u) + (threadIdx.x >> 6);
+        waves = (unsigned long long)gridDim.x * (blockDim.x / 64u);
+        wave_id = (unsigned long long)blockIdx.x * (blockDim.x / 64u) + (threadIdx.x >> 6);
         const unsigned long long k = n / (waves * RANGES_PER_WAVE * 64ull);
         len = 64ull * (k < 1ull ? 1ull : (k > 16ull ? 16ull : k));
-        first_base = wave_id * len;
+        short_len = 64ull * (len / 256ull < 1ull ? 1ull : len / 256ull);
+        n_long = (n - n / 4ull) / len; // ranges of full length; range g >= n_long starts at n_long*len + (g - n_long)*short_len
         slots = gridDim.x < (uint32_t)WORK_SLOTS ? gridDim.x : (uint32_t)WORK_SLOTS; // every residue class needs a taker
         slot = blockIdx.x % slots;
-        dynamic_base = (waves + slot) * len;
     }
-    // Next range [base, base + len) of this wave; base >= n when the batch is finished.  `counters` is the
+    // Next range [base, base + length) of this wave; base >= n when the batch is finished.  `counters` is the
     // scene's counter block (statistics words, then the work slots).
-    __device__ __forceinline__ unsigned long long next(unsigned long long* counters) {
-        if (!started) { started = true; return first_base; }
-        if (dynamic_base >= n) return n;
-        return dynamic_base + wave_fetch(counters + C_WORK_SLOTS + slot * WORK_STRIDE, 1ull) * (unsigned long long)slots * len;
+    __device__ __forceinline__ unsigned long long next(unsigned long long* counters, unsigned long long& length) {
+        unsigned long long g; // index of the range in queue order
+        if (!started) { started = true; g = wave_id; }
+        else {
+            // cheap exit without an atomic when even this slot's first dynamic range lies beyond the batch
+            if (n_long * len + (waves + slot >= n_long ? (waves + slot - n_long) * short_len : 0ull) >= n && waves + slot >= n_long) { length = 0; return n; }
+            g = waves + slot + wave_fetch(counters + C_WORK_SLOTS + slot * WORK_STRIDE, 1ull) * (unsigned long long)slots;
+        }
+        if (g < n_long) { length = len; return g * len; }
+        length = short_len;
+        return n_long * len + (g - n_long) * short_len;
     }
 };
 
@@ -133,9 +142,9 @@ __global__ __launch_bounds__(BLOCK) void closest_hit_kernel(DScene S, rt_ray_bat
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t nn = 0, np = 0;
     WaveWork work(n);
-    const unsigned long long chunk = work.len;
     for (;;) {
-        const unsigned long long base = work.next(counters);
+        unsigned long long chunk;
+        const unsigned long long base = work.next(counters, chunk);
         if (base >= n) break;
         for (unsigned long long off = 0; off < chunk; off += 64ull) {
         unsigned long long i = base + off + lane;
@@ -268,9 +277,9 @@ __global__ __launch_bounds__(BLOCK, 3) void extend_kernel(DScene S, PathState ps
 #define RT_PHASE(k) do { } while (0)
 #endif
     WaveWork work(n);
-    const unsigned long long chunk = work.len;
     for (;;) {
-        const unsigned long long base = work.next(ps.counters);
+        unsigned long long chunk;
+        const unsigned long long base = work.next(ps.counters, chunk);
         RT_PHASE(0);
         if (base >= n) break;
         uint32_t p_next = base + lane < n ? queue[base + lane] : 0u; // the queue entry is read one wave-load ahead of its record
