@@ -89,10 +89,6 @@ __device__ __forceinline__ unsigned long long wave_fetch(unsigned long long* cou
     return ((unsigned long long)hi << 32) | lo;
 }
 
-// Rays a wave takes from the global counter per atomic: all waves increment the same word, and the chip
-// serves same-address atomics at roughly 10 ns each, so one atomic per 64 rays alone would cap a kernel
-// near 6 G rays/s.  Up to 16 wave-loads per fetch, fewer when the batch is small, so that every wave
-// still gets several fetches.
 // Work distribution of the persistent kernels.  The chip serves same-address atomics at roughly 10 ns each:
 // with one counter for all waves, one atomic per 64 rays caps a kernel near 6 G rays/s, and at launch, when
 // every wave asks at the same moment, the last in line waits tens of microseconds.  So a range is up to 16
