@@ -130,7 +130,8 @@ struct WaveWork {
     }
 };
 
-template <bool COUNT, bool ORDERED>
+// MEDIA = false: the scene holds no constant medium; the nested boundary queries and the random draw are compiled out.
+template <bool COUNT, bool ORDERED, bool MEDIA>
 __global__ __launch_bounds__(BLOCK) void closest_hit_kernel(DScene S, rt_ray_batch rays, unsigned long long n, rt_hit_batch hits,
                                                             unsigned long long seed, unsigned long long* counters) {
     __shared__ uint32_t s_stack[STACK_MAX * BLOCK];
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(BLOCK) void closest_hit_kernel(DScene S, rt_ray_bat
             b.t = rays.tmax ? rays.tmax[i] : D_INF;
             b.ref = RT_REF_NONE; b.ctx = 0;
             Rng g{seed, 2u, (uint32_t)i, (uint32_t)(i >> 32), 0u};
-            traverse<true, COUNT, ORDERED>(S, S.world, r, 0, w, time, tmin, b, stk, 0, &g, nn, np);
+            traverse<MEDIA, COUNT, ORDERED>(S, S.world, r, 0, w, time, tmin, b, stk, 0, &g, nn, np);
             if (b.ref != RT_REF_NONE) {
                 HitRec h;
                 finalize(S, w, time, b, h);
@@ -590,7 +591,8 @@ int pick_grid(rt_scene* s) {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, s->device));
     int per_cu = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, closest_hit_kernel<false, true>, BLOCK, 0));
+    if (s->flat.has_medium) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, closest_hit_kernel<false, true, true>, BLOCK, 0));
+    else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, closest_hit_kernel<false, true, false>, BLOCK, 0));
     int per_cu2 = 0;
     if (s->flat.has_medium) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, extend_kernel<true>, BLOCK, 0));
     else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, extend_kernel<false>, BLOCK, 0));
@@ -743,10 +745,17 @@ int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit
     auto launch = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3(blocks), dim3(BLOCK), 0, st, s->dev, *rays, (unsigned long long)n, *hits, (unsigned long long)seed, s->d_counters);
     };
-    if (count && ordered) launch(closest_hit_kernel<true, true>);
-    else if (count) launch(closest_hit_kernel<true, false>);
-    else if (ordered) launch(closest_hit_kernel<false, true>);
-    else launch(closest_hit_kernel<false, false>);
+    if (s->flat.has_medium) {
+        if (count && ordered) launch(closest_hit_kernel<true, true, true>);
+        else if (count) launch(closest_hit_kernel<true, false, true>);
+        else if (ordered) launch(closest_hit_kernel<false, true, true>);
+        else launch(closest_hit_kernel<false, false, true>);
+    } else {
+        if (count && ordered) launch(closest_hit_kernel<true, true, false>);
+        else if (count) launch(closest_hit_kernel<true, false, false>);
+        else if (ordered) launch(closest_hit_kernel<false, true, false>);
+        else launch(closest_hit_kernel<false, false, false>);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev_hit1, st));
     s->hit_timed = true;
