@@ -1,12 +1,15 @@
 // mi355rt.hip -- HIP kernels (gfx950) and the C ABI of libmi355rt.so.
 //
 // Kernels
-//   closest_hit_kernel  batched world.hit (camera.rs:258 / hittable.rs:49): persistent waves fetch
-//                       64-ray chunks from a global counter, one ray per lane, LDS stack.
+//   closest_hit_kernel  batched world.hit (camera.rs:258 / hittable.rs:49) for any scene: persistent waves take
+//                       ranges of the batch (WaveWork), one ray per lane, LDS stack, full hit record.
+//   bvh4_closest_hit_kernel (bvh_kernel.h)  the same query when the world is one BVH over primitives; followed by
+//                       finalize_hits_kernel, which completes the records in one coalesced pass.
 //   raygen_kernel       Camera::get_ray (camera.rs:207-240) for every (pixel, stratum) of a batch.
 //   extend_kernel       closest hit for the live paths of the current bounce (queue of path ids).
 //   shade_kernel        one bounce of Camera::ray_color (camera.rs:243-339) + wave-level
 //                       ballot compaction of the surviving paths into the next queue.
+//   tail_kernel         the last bounces of a batch in one launch (each lane follows its path to the end).
 //   accumulate_kernel   pixel_color += ray_color(...) in stratum order (camera.rs:110-131).
 // The product path has no CPU fallback: every entry point that computes needs a HIP device.
 #include <hip/hip_runtime.h>
