@@ -350,8 +350,10 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, 
     }
 }
 
-// Completes HitRecord fields for a batch whose (t, prim) are already written (transform context 0).
-__global__ __launch_bounds__(256) void finalize_hits_kernel(DScene S, rt_ray_batch rays, unsigned long long n, rt_hit_batch hits) {
+// Completes HitRecord fields for a batch whose (t, prim) are already written; `ctx`: transform context of every
+// hit (null: all in the world's own context).  prim is rewritten, because a constant medium is reported by its
+// object id, not by the internal reference the traversal leaves.
+__global__ __launch_bounds__(256) void finalize_hits_kernel(DScene S, rt_ray_batch rays, unsigned long long n, rt_hit_batch hits, const int32_t* ctx) {
     const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t prim = hits.prim[i];
@@ -370,9 +372,10 @@ __global__ __launch_bounds__(256) void finalize_hits_kernel(DScene S, rt_ray_bat
     }
     WorldRay w{rays.ox, rays.oy, rays.oz, rays.dx, rays.dy, rays.dz, i};
     Best b;
-    b.t = hits.t[i]; b.ref = prim; b.ctx = 0;
+    b.t = hits.t[i]; b.ref = prim; b.ctx = ctx ? ctx[i] : 0;
     HitRec h;
     finalize(S, w, rays.time ? rays.time[i] : 0.0, b, h);
+    hits.prim[i] = h.prim;
     if (hits.u) hits.u[i] = h.u;
     if (hits.v) hits.v[i] = h.v;
     if (hits.front_face) hits.front_face[i] = h.front_face ? 1 : 0;

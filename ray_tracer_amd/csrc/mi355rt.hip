@@ -136,7 +136,7 @@ struct WaveWork {
 // MEDIA = false: the scene holds no constant medium; the nested boundary queries and the random draw are compiled out.
 template <bool COUNT, bool ORDERED, bool MEDIA>
 __global__ __launch_bounds__(BLOCK) void closest_hit_kernel(DScene S, rt_ray_batch rays, unsigned long long n, rt_hit_batch hits,
-                                                            unsigned long long seed, unsigned long long* counters) {
+                                                            int32_t* hit_ctx, unsigned long long seed, unsigned long long* counters) {
     __shared__ uint32_t s_stack[STACK_MAX * BLOCK];
     uint32_t* stk = s_stack + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
@@ -159,35 +159,12 @@ __global__ __launch_bounds__(BLOCK) void closest_hit_kernel(DScene S, rt_ray_bat
             b.ref = RT_REF_NONE; b.ctx = 0;
             Rng g{seed, 2u, (uint32_t)i, (uint32_t)(i >> 32), 0u};
             traverse<MEDIA, COUNT, ORDERED>(S, S.world, r, 0, w, time, tmin, b, stk, 0, &g, nn, np);
-            if (b.ref != RT_REF_NONE) {
-                HitRec h;
-                finalize(S, w, time, b, h);
-                hits.t[i] = h.t;
-                hits.prim[i] = h.prim;
-                if (hits.u) hits.u[i] = h.u;
-                if (hits.v) hits.v[i] = h.v;
-                if (hits.front_face) hits.front_face[i] = h.front_face ? 1 : 0;
-                if (hits.mat) hits.mat[i] = h.mat;
-                if (hits.nx) hits.nx[i] = h.normal.x;
-                if (hits.ny) hits.ny[i] = h.normal.y;
-                if (hits.nz) hits.nz[i] = h.normal.z;
-                if (hits.px) hits.px[i] = h.p.x;
-                if (hits.py) hits.py[i] = h.p.y;
-                if (hits.pz) hits.pz[i] = h.p.z;
-            } else {
-                hits.t[i] = D_INF;
-                hits.prim[i] = RT_REF_NONE;
-                if (hits.u) hits.u[i] = 0.0;
-                if (hits.v) hits.v[i] = 0.0;
-                if (hits.front_face) hits.front_face[i] = 0;
-                if (hits.mat) hits.mat[i] = -1;
-                if (hits.nx) hits.nx[i] = 0.0;
-                if (hits.ny) hits.ny[i] = 0.0;
-                if (hits.nz) hits.nz[i] = 0.0;
-                if (hits.px) hits.px[i] = 0.0;
-                if (hits.py) hits.py[i] = 0.0;
-                if (hits.pz) hits.pz[i] = 0.0;
-            }
+            // (t, what was hit, in which transform context): finalize_hits_kernel completes the record in a pass of
+            // its own, which keeps the record arithmetic (acos, atan2, the transform unwinding) out of this
+            // kernel's register budget
+            hits.t[i] = b.ref != RT_REF_NONE ? b.t : D_INF;
+            hits.prim[i] = b.ref;
+            hit_ctx[i] = b.ctx;
         }
         }
     }
@@ -537,6 +514,8 @@ struct rt_scene {
     int extend_blocks = 0, shade_blocks = 0, tail_blocks = 0;
     size_t fast_lds = 0;
     uint2* fast_spill = nullptr; // HBM overflow of the per-lane stacks: [entry][thread]
+    int32_t* hit_ctx = nullptr;  // transform context of every hit of the current general closest-hit batch
+    uint64_t hit_ctx_cap = 0;
     int fast_prim = 0;           // leaf kind of the primitive BVH when uniform, else 0
     bool fast_quant = false;     // the primitive-BVH kernel reads the 64-byte nodes with 8-bit boxes
     float fast_extent = 0.0f; // largest |coordinate| stored in the 4-wide nodes (error bound of the f32 slab test)
@@ -739,14 +718,22 @@ int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(s->ev_hit1, st));
         if (hits->u || hits->v || hits->front_face || hits->mat || hits->nx || hits->ny || hits->nz || hits->px || hits->py || hits->pz)
-            hipLaunchKernelGGL(finalize_hits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s->dev, *rays, (unsigned long long)n, *hits);
+            hipLaunchKernelGGL(finalize_hits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s->dev, *rays, (unsigned long long)n, *hits, (const int32_t*)nullptr);
         HIP_TRY(hipGetLastError());
         s->hit_timed = true;
         s->counters.rays += n;
         return RT_OK;
     }
+    if (s->hit_ctx_cap < n) { // scratch between the traversal and the record-completion pass, grown to the largest batch seen
+        if (s->hit_ctx) (void)hipFree(s->hit_ctx);
+        s->hit_ctx = nullptr; s->hit_ctx_cap = 0;
+        void* p = nullptr;
+        HIP_TRY(hipMalloc(&p, n * sizeof(int32_t)));
+        s->hit_ctx = static_cast<int32_t*>(p);
+        s->hit_ctx_cap = n;
+    }
     auto launch = [&](auto kernel) {
-        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(BLOCK), 0, st, s->dev, *rays, (unsigned long long)n, *hits, (unsigned long long)seed, s->d_counters);
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(BLOCK), 0, st, s->dev, *rays, (unsigned long long)n, *hits, s->hit_ctx, (unsigned long long)seed, s->d_counters);
     };
     if (s->flat.has_medium) {
         if (count && ordered) launch(closest_hit_kernel<true, true, true>);
@@ -759,6 +746,7 @@ int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit
         else if (ordered) launch(closest_hit_kernel<false, true, false>);
         else launch(closest_hit_kernel<false, false, false>);
     }
+    hipLaunchKernelGGL(finalize_hits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s->dev, *rays, (unsigned long long)n, *hits, (const int32_t*)s->hit_ctx);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev_hit1, st));
     s->hit_timed = true;
@@ -909,6 +897,7 @@ int rt_scene_destroy(rt_scene* s) {
         (void)hipSetDevice(s->device);
         free_workspace(s);
         for (void* p : s->allocs) (void)hipFree(p);
+        if (s->hit_ctx) (void)hipFree(s->hit_ctx);
         if (s->h_counters) (void)hipHostFree(s->h_counters);
         if (s->ev_hit0) (void)hipEventDestroy(s->ev_hit0);
         if (s->ev_hit1) (void)hipEventDestroy(s->ev_hit1);
