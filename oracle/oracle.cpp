@@ -142,8 +142,9 @@ static inline Vec3 random_cosine_direction() { // used by pdf.rs:58
     double r1 = random_double();
     double r2 = random_double();
     double phi = 2.0 * PI * r1;
+    volatile double phi_again = phi; // keeps cos and sin two libm calls, as in the reference (see RotateY)
     double x = std::cos(phi) * std::sqrt(r2);
-    double y = std::sin(phi) * std::sqrt(r2);
+    double y = std::sin(phi_again) * std::sqrt(r2);
     double z = std::sqrt(1.0 - r2);
     return Vec3(x, y, z);
 }
@@ -497,8 +498,9 @@ struct Sphere : Hittable { // sphere.rs:12-142
         double r2 = random_double();
         double z = 1.0 + r2 * (std::sqrt(1.0 - radius * radius / distance_squared) - 1.0);
         double phi = 2.0 * PI * r1;
+        volatile double phi_again = phi; // two libm calls, as in the reference (see RotateY)
         double x = std::cos(phi) * std::sqrt(1.0 - z * z);
-        double y = std::sin(phi) * std::sqrt(1.0 - z * z);
+        double y = std::sin(phi_again) * std::sqrt(1.0 - z * z);
         return Vec3(x, y, z);
     }
     bool hit(const Ray& r, Interval ray_t, HitRecord& rec) const override { // sphere.rs:72-111
@@ -750,8 +752,12 @@ struct RotateY : Hittable { // hittable.rs:96-187
     HittablePtr object; double sin_theta, cos_theta; Aabb bbox;
     RotateY(HittablePtr o, double angle) : object(o) {
         double radians = angle * (PI / 180.0); // f64::to_radians
+        // two separate libm calls, as the reference makes them (hittable.rs:106-108): g++ would otherwise merge the
+        // pair into one sincos() call, and glibc's sincos differs from its sin / cos in the last place for about one
+        // argument in 750
+        volatile double radians_again = radians;
         sin_theta = std::sin(radians);
-        cos_theta = std::cos(radians);
+        cos_theta = std::cos(radians_again);
         Aabb b = o->bounding_box();
         Point3 mn(INF, INF, INF), mx(-INF, -INF, -INF);
         for (int i = 0; i < 2; ++i)

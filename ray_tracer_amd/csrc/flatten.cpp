@@ -361,7 +361,8 @@ struct Flattener {
                 if (!child_ok(o.a)) return fail(RT_E_INVALID, "rotate_y: bad child");
                 const Box& c = f.object_bounds[o.a];
                 double radians = o.param[0] * (PI / 180.0); // f64::to_radians
-                double sin_theta = std::sin(radians), cos_theta = std::cos(radians);
+                volatile double radians_again = radians; // two libm calls whatever the compiler (glibc's sincos differs from sin / cos in the last place now and then)
+                double sin_theta = std::sin(radians), cos_theta = std::cos(radians_again);
                 double mn[3] = {INF, INF, INF}, mx[3] = {-INF, -INF, -INF};
                 for (int ii = 0; ii < 2; ++ii)
                     for (int jj = 0; jj < 2; ++jj)
@@ -490,7 +491,8 @@ struct Flattener {
             if (o.kind == RT_OBJ_TRANSLATE) { x.kind = 0; x.a[0] = o.param[0]; x.a[1] = o.param[1]; x.a[2] = o.param[2]; }
             else {
                 double radians = o.param[0] * (PI / 180.0); // hittable.rs:106
-                x.kind = 1; x.a[0] = std::sin(radians); x.a[1] = std::cos(radians); x.a[2] = 0.0;
+                volatile double radians_again = radians; // two libm calls, as the reference makes them (hittable.rs:106-108)
+                x.kind = 1; x.a[0] = std::sin(radians); x.a[1] = std::cos(radians_again); x.a[2] = 0.0;
             }
             size_t xi = f.xforms.size();
             f.xforms.push_back(x);

@@ -1,0 +1,12 @@
+"""Random scene graphs (nested lists, BVHs over mixed children, boxes, transform chains, media) against the oracle,
+both traversal orders, incoherent batches and batches in which whole waves trace the same ray."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_random_scene_graphs_match_the_oracle():
+    import fuzz_scenes
+    for seed in (2, 7):  # seed 2, scene 54 holds a RotateY angle at which glibc's sincos() and sin()/cos() differ in the last place
+        done, failed = fuzz_scenes.run(80, seed)
+        assert done >= 70 and not failed, failed
