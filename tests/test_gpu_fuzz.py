@@ -10,3 +10,11 @@ def test_random_scene_graphs_match_the_oracle():
     for seed in (2, 7):  # seed 2, scene 54 holds a RotateY angle at which glibc's sincos() and sin()/cos() differ in the last place
         done, failed = fuzz_scenes.run(80, seed)
         assert done >= 70 and not failed, failed
+
+
+def test_random_scenes_render_like_the_oracle():
+    """Random scene graphs with random materials (diffuse, checker, metal, glass, media), light lists of a quad and
+    sometimes a sphere, random cameras: at most one pixel in 200 may differ from the oracle beyond rounding."""
+    import fuzz_render
+    done, failed = fuzz_render.run(60, 5)
+    assert done >= 50 and not failed, failed
