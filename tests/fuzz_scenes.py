@@ -11,8 +11,14 @@ from ray_tracer_amd import _ffi as F, scenes
 from test_gpu_closest_hit import compare
 
 def rand_prim(g, m):
-    k = g.integers(0, 4)
+    k = g.integers(0, 7)
     c = g.uniform(-4, 4, 3)
+    if k == 4:
+        return rt.Sphere.new_moving(rt.Point3(*c), rt.Point3(*(c + g.uniform(-.7, .7, 3))), float(g.uniform(0.2, 0.8)), m)
+    if k == 5:  # a small mesh: a BVH over triangles of its own (mesh.rs:163)
+        return rt.Mesh(scenes.triangle_soup(int(g.integers(1, 40)), seed=int(g.integers(1 << 20)), edge=0.8) * 2.0 + c, m)
+    if k == 6:  # the same triangles as a flat list (obj_loader.rs:46-75)
+        return rt.ObjModel(scenes.triangle_soup(int(g.integers(1, 12)), seed=int(g.integers(1 << 20)), edge=0.8) * 2.0 + c, m)
     if k == 0:
         return rt.Sphere(rt.Point3(*c), float(g.uniform(0.2, 0.8)), m)
     if k == 1:
