@@ -153,7 +153,7 @@ struct DScene {
     int32_t lights_is_list;    // 1: HittableList semantics (uniform pick / mean pdf), 0: a single object
     float q_extent;            // largest |coordinate| stored in the 4-wide nodes (margin of the f32 slab test)
     uint32_t uses_uv;          // some texture reads the surface coordinates u,v (an image texture exists)
-    uint32_t _pad;
+    uint32_t world_rest;       // the world list without its first member (RT_REF_NONE unless that member is traced by the primitive-BVH kernel)
 };
 
 } // namespace rt

@@ -39,6 +39,10 @@ struct FlatScene {
     uint32_t max_stack = 0;
     uint32_t fast_root = RT_REF_NONE; // set when the world is one BVH whose leaves are all primitives
     uint32_t fast_stack = 0;          // stack entries the primitive-BVH kernel needs
+    bool fast_partial = false;        // fast_root covers only the FIRST member of the world list (rebuilt as one BVH over its
+                                      // primitives); `world_rest` is the list of the remaining members, traversed afterwards
+                                      // with the first member's closest hit as the interval's upper end (list order: hittable_list.rs:46-57)
+    uint32_t world_rest = RT_REF_NONE;
     float q_extent = 0.0f;            // largest |coordinate| in qnodes
     double quant_inflation = 0.0;     // mean surface-area ratio of the 8-bit child boxes to their f32 boxes
     bool has_medium = false;

@@ -237,7 +237,8 @@ __global__ __launch_bounds__(BLOCK) void raygen_kernel(CamD cam, BatchGeom bg, P
 // At least 3 waves per SIMD (168 registers): the variant with media sits within a few registers of that limit,
 // and one wave less costs it more than 10 %.
 template <bool MEDIA>
-__global__ __launch_bounds__(BLOCK, 3) void extend_kernel(DScene S, PathState ps, int qsel, unsigned long long seed, BatchGeom bg, int32_t image_width) {
+__global__ __launch_bounds__(BLOCK, 3) void extend_kernel(DScene S, PathState ps, int qsel, unsigned long long seed, BatchGeom bg, int32_t image_width,
+                                                          int rest_only) {
     __shared__ uint32_t s_stack[STACK_MAX * BLOCK];
     uint32_t* stk = s_stack + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
@@ -276,6 +277,11 @@ __global__ __launch_bounds__(BLOCK, 3) void extend_kernel(DScene S, PathState ps
             RT_PHASE(1);
             Best b;
             b.t = D_INF; b.ref = RT_REF_NONE; b.ctx = 0;
+            uint32_t root = S.world;
+            if (rest_only) { // the primitive-BVH kernel has traced the world's first member: go on from its closest hit
+                b.t = rec->hit_t; b.ref = rec->hit_ref;
+                root = S.world_rest;
+            }
             uint32_t s_local = p / bg.npix, pix = p - s_local * bg.npix;
             int32_t i = bg.x0 + (int32_t)(pix % (uint32_t)bg.tw);
             int32_t j = bg.y0 + (int32_t)(pix / (uint32_t)bg.tw);
@@ -283,7 +289,7 @@ __global__ __launch_bounds__(BLOCK, 3) void extend_kernel(DScene S, PathState ps
 #ifdef RT_PHASE_STATS
             s_lane_iters[threadIdx.x] = 0u;
 #endif
-            traverse<MEDIA, false, true, true, !MEDIA>(S, S.world, r, 0, w, time, 0.001, b, stk, 0, &g, nn, np); // Interval::new(0.001, INFINITY) (camera.rs:258)
+            traverse<MEDIA, false, true, true, !MEDIA>(S, root, r, 0, w, time, 0.001, b, stk, 0, &g, nn, np); // Interval::new(0.001, INFINITY) (camera.rs:258)
             RT_PHASE(2);
 #ifdef RT_PHASE_STATS
             {
@@ -618,7 +624,7 @@ void fill_host_dscene(rt_scene* s) {
     d.lists = f.lists.data(); d.list_items = f.list_items.data(); d.xforms = f.xforms.data();
     d.media = f.media.data(); d.materials = f.materials.data(); d.textures = f.textures.data(); d.images = f.images.data();
     d.image_bytes = f.image_bytes.data(); d.perlins = f.perlins.data(); d.lights = f.lights.data();
-    d.world = f.world; d.n_lights = f.n_lights; d.lights_is_list = f.lights_is_list; d.q_extent = f.q_extent; d.uses_uv = f.uses_uv ? 1u : 0u; d._pad = 0;
+    d.world = f.world; d.n_lights = f.n_lights; d.lights_is_list = f.lights_is_list; d.q_extent = f.q_extent; d.uses_uv = f.uses_uv ? 1u : 0u; d.world_rest = f.world_rest;
 }
 
 int upload_scene(rt_scene* s) {
@@ -647,7 +653,7 @@ int upload_scene(rt_scene* s) {
     if ((rc = upload(s, f.image_bytes, &d.image_bytes))) return rc;
     if ((rc = upload(s, f.perlins, &d.perlins))) return rc;
     if ((rc = upload(s, f.lights, &d.lights))) return rc;
-    d.world = f.world; d.n_lights = f.n_lights; d.lights_is_list = f.lights_is_list; d.q_extent = f.q_extent; d.uses_uv = f.uses_uv ? 1u : 0u; d._pad = 0;
+    d.world = f.world; d.n_lights = f.n_lights; d.lights_is_list = f.lights_is_list; d.q_extent = f.q_extent; d.uses_uv = f.uses_uv ? 1u : 0u; d.world_rest = f.world_rest;
     void* c = nullptr;
     HIP_TRY(hipMalloc(&c, C_ALLOC * sizeof(unsigned long long)));
     s->allocs.push_back(c);
@@ -703,7 +709,7 @@ int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit
     int blocks = (int)std::min<uint64_t>((uint64_t)s->grid_blocks, (waves + (BLOCK / 64) - 1) / (BLOCK / 64));
     HIP_TRY(hipEventRecord(s->ev_hit0, st));
     const bool count = flags & RT_HIT_COUNTERS, ordered = flags & RT_HIT_ORDERED;
-    if (ordered && s->flat.fast_root != RT_REF_NONE) {
+    if (ordered && s->flat.fast_root != RT_REF_NONE && !s->flat.fast_partial) {
         // the world is one BVH over primitives: dedicated traversal kernel + one pass that completes the records
         int fblocks = (int)std::min<uint64_t>((uint64_t)s->fast_grid_blocks, (waves + (FAST_BLOCK / 64) - 1) / (FAST_BLOCK / 64));
         RayQueue rq{nullptr, nullptr};
@@ -829,9 +835,11 @@ int render_impl(rt_scene* s, const rt_camera* cam, uint64_t seed, const rt_work*
                     hipLaunchKernelGGL(fast_kernel_paths(s->fast_prim, s->fast_quant), dim3(fblocks), dim3(FAST_BLOCK), 0, st, s->dev, s->flat.fast_root,
                                        view, (unsigned long long)live, rq, 1u, 0.001, s->fast_extent, out_t, out_prim, s->d_counters + C_WORK_SLOTS,
                                        s->d_counters + C_NODES, s->fast_spill, k_refill, k_vote, k_chunk, k_pop);
-                } else {
+                }
+                if (!fast_extend || s->flat.fast_partial) { // the whole world, or what follows its first member
+                    if (fast_extend) hipLaunchKernelGGL(reset_work_kernel, dim3(1), dim3(1), 0, st, s->d_counters);
                     hipLaunchKernelGGL(s->flat.has_medium ? extend_kernel<true> : extend_kernel<false>, dim3(blocks), dim3(BLOCK), 0, st, s->dev, ps, qsel,
-                                       (unsigned long long)seed, bg, cam->image_width);
+                                       (unsigned long long)seed, bg, cam->image_width, fast_extend ? 1 : 0);
                 }
                 hipLaunchKernelGGL(has_tex ? shade_kernel<true> : shade_kernel<false>, dim3(sblocks), dim3(BLOCK), 0, st, s->dev, cd, ps, qsel, (unsigned long long)seed, bg, bounce == cam->max_depth - 1 ? 1 : 0);
                 hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, st, s->d_counters);
