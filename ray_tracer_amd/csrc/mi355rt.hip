@@ -136,7 +136,7 @@ struct WaveWork {
 // MEDIA = false: the scene holds no constant medium; the nested boundary queries and the random draw are compiled out.
 template <bool COUNT, bool ORDERED, bool MEDIA>
 __global__ __launch_bounds__(BLOCK) void closest_hit_kernel(DScene S, rt_ray_batch rays, unsigned long long n, rt_hit_batch hits,
-                                                            int32_t* hit_ctx, unsigned long long seed, unsigned long long* counters) {
+                                                            int32_t* hit_ctx, unsigned long long seed, unsigned long long* counters, int rest_only) {
     __shared__ uint32_t s_stack[STACK_MAX * BLOCK];
     uint32_t* stk = s_stack + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
@@ -158,7 +158,13 @@ __global__ __launch_bounds__(BLOCK) void closest_hit_kernel(DScene S, rt_ray_bat
             b.t = rays.tmax ? rays.tmax[i] : D_INF;
             b.ref = RT_REF_NONE; b.ctx = 0;
             Rng g{seed, 2u, (uint32_t)i, (uint32_t)(i >> 32), 0u};
-            traverse<MEDIA, COUNT, ORDERED>(S, S.world, r, 0, w, time, tmin, b, stk, 0, &g, nn, np);
+            uint32_t root = S.world;
+            if (rest_only) { // the primitive-BVH kernel has traced the world's first member into hits.t / hits.prim
+                const uint32_t first_hit = hits.prim[i];
+                if (first_hit != RT_REF_NONE) { b.t = hits.t[i]; b.ref = first_hit; }
+                root = S.world_rest;
+            }
+            traverse<MEDIA, COUNT, ORDERED>(S, root, r, 0, w, time, tmin, b, stk, 0, &g, nn, np);
             // (t, what was hit, in which transform context): finalize_hits_kernel completes the record in a pass of
             // its own, which keeps the record arithmetic (acos, atan2, the transform unwinding) out of this
             // kernel's register budget
@@ -738,8 +744,23 @@ int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit
         s->hit_ctx = static_cast<int32_t*>(p);
         s->hit_ctx_cap = n;
     }
+    // ordered traversal of a world whose first member has a primitive BVH of its own: that member through the
+    // primitive-BVH kernel, the rest through the general one, which starts from the first member's closest hit
+    const bool split = ordered && !count && s->flat.fast_root != RT_REF_NONE && s->flat.fast_partial;
+    if (split) {
+        int fblocks = (int)std::min<uint64_t>((uint64_t)s->fast_grid_blocks, (waves + (FAST_BLOCK / 64) - 1) / (FAST_BLOCK / 64));
+        RayQueue rq{nullptr, nullptr};
+        const uint32_t opt = (rays->time ? 1u : 0u) | (rays->tmin ? 2u : 0u) | (rays->tmax ? 4u : 0u);
+        hipLaunchKernelGGL(fast_kernel(s->fast_prim, false, s->fast_quant), dim3(fblocks), dim3(FAST_BLOCK), 0, st, s->dev, s->flat.fast_root, *rays,
+                           (unsigned long long)n, rq, opt, 0.001, s->fast_extent, hits->t, hits->prim, s->d_counters + C_WORK_SLOTS, s->d_counters + C_NODES,
+                           s->fast_spill, env_int("MI355RT_REFILL", REFILL_THRESHOLD), env_int("MI355RT_VOTE", LEAF_VOTE), env_int("MI355RT_CHUNK", 0),
+                           env_int("MI355RT_POP_TRIPS", POP_TRIPS));
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemsetAsync(s->d_counters + C_WORK_SLOTS, 0, WORK_SLOTS * WORK_STRIDE * sizeof(unsigned long long), st));
+    }
     auto launch = [&](auto kernel) {
-        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(BLOCK), 0, st, s->dev, *rays, (unsigned long long)n, *hits, s->hit_ctx, (unsigned long long)seed, s->d_counters);
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(BLOCK), 0, st, s->dev, *rays, (unsigned long long)n, *hits, s->hit_ctx, (unsigned long long)seed, s->d_counters,
+                           split ? 1 : 0);
     };
     if (s->flat.has_medium) {
         if (count && ordered) launch(closest_hit_kernel<true, true, true>);
