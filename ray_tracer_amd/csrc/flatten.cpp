@@ -584,62 +584,75 @@ struct Flattener {
     // and the general traversal then walks the remaining members with that hit as the interval's upper end, which
     // is the order HittableList::hit visits them in (hittable_list.rs:46-57).  The closest hit over a set of
     // primitives does not depend on the tree over them (ties aside, as everywhere in the ordered traversal).
+    bool hoist_whole_world = false; // set by hoist_first_member: the extra BVH covers every member of the world list
     int hoist_first_member(int64_t& root_out) {
         root_out = -1;
         if (RT_REF_KIND(f.world) != RT_REF_LIST) return RT_OK;
         const DList w = f.lists[RT_REF_INDEX(f.world)];
         if (w.count < 2u) return RT_OK;
+        // Primitives below `start`, or false when an instance or a medium lies below it.
+        auto gather = [&](uint32_t start, std::vector<Item>& items) -> bool {
+            std::vector<uint32_t> todo{start};
+            while (!todo.empty()) {
+                const uint32_t r = todo.back(); todo.pop_back();
+                const uint32_t k = RT_REF_KIND(r), i = RT_REF_INDEX(r);
+                if (k == RT_REF_NODE) {
+                    const DNode& n = f.nodes[i];
+                    if (n.flags & 1u) return false; // a medium below: keep the reference order
+                    todo.push_back(n.left);
+                    if (n.right != n.left) todo.push_back(n.right); // a one-object span stores the object twice (bvh.rs:41-44)
+                } else if (k == RT_REF_SPHERE || k == RT_REF_QUAD || k == RT_REF_TRI) {
+                    Item it; it.ref = r; it.medium = 0;
+                    it.box = k == RT_REF_SPHERE ? sphere_box(i) : (k == RT_REF_QUAD ? quad_box(i) : tri_box(i));
+                    items.push_back(it);
+                } else if (k == RT_REF_LIST) {
+                    const DList l = f.lists[i];
+                    for (uint32_t j = 0; j < l.count; ++j) todo.push_back(f.list_items[l.first + j]);
+                } else {
+                    return false; // instances, media: not hoisted
+                }
+            }
+            for (auto& it : items) {
+                if (box_has_nan(it.box)) return false;
+                for (double v : it.box.b) if (!std::isfinite(v)) return false;
+            }
+            return true;
+        };
+        auto build = [&](std::vector<Item>& items) -> int64_t {
+            const uint64_t count = bvh_node_count(items.size());
+            const uint64_t base = f.nodes.size();
+            if (base + count >= (1ull << 28)) return -1;
+            f.nodes.resize(base + count);
+            f.wnodes.resize(base + count);
+            build_bvh(items, 0, items.size(), f.nodes.data() + base, f.wnodes.data() + base, base, 0, 0);
+            bvh_roots.push_back((uint32_t)base);
+            return (int64_t)base;
+        };
+        // (1) A world without instances and media: the closest hit over all its primitives does not depend on the
+        //     order of the list, so ONE BVH over all of them replaces the whole walk (mesh + spheres: two BVHs in a list).
+        if (!f.has_medium) {
+            std::vector<Item> all;
+            if (gather(f.world, all) && all.size() >= 64u) {
+                root_out = build(all);
+                hoist_whole_world = root_out >= 0;
+                return RT_OK;
+            }
+        }
+        // (2) Otherwise the first member alone, when it is such a BVH.
         const uint32_t first = f.list_items[w.first];
         if (RT_REF_KIND(first) != RT_REF_NODE) return RT_OK;
         auto po = bvh_prim_only.find(first);
         const bool prim_only = po != bvh_prim_only.end() && po->second;
         std::vector<Item> items;
-        std::vector<uint32_t> todo{first};
-        auto add_prim = [&](uint32_t r) {
-            Item it; it.ref = r; it.medium = 0;
-            const uint32_t k = RT_REF_KIND(r), i = RT_REF_INDEX(r);
-            it.box = k == RT_REF_SPHERE ? sphere_box(i) : (k == RT_REF_QUAD ? quad_box(i) : tri_box(i));
-            items.push_back(it);
-        };
-        while (!todo.empty()) {
-            const uint32_t r = todo.back(); todo.pop_back();
-            const uint32_t k = RT_REF_KIND(r);
-            if (k == RT_REF_NODE) {
-                const DNode& n = f.nodes[RT_REF_INDEX(r)];
-                if (n.flags & 1u) return RT_OK; // a medium below: keep the reference order
-                todo.push_back(n.left);
-                if (n.right != n.left) todo.push_back(n.right); // a one-object span stores the object twice (bvh.rs:41-44)
-            } else if (k == RT_REF_SPHERE || k == RT_REF_QUAD || k == RT_REF_TRI) {
-                add_prim(r);
-            } else if (k == RT_REF_LIST) {
-                const DList l = f.lists[RT_REF_INDEX(r)];
-                for (uint32_t j = 0; j < l.count; ++j) todo.push_back(f.list_items[l.first + j]);
-            } else {
-                return RT_OK; // instances, media: not hoisted
-            }
-        }
+        if (!gather(first, items)) return RT_OK;
         // too small to pay for a second launch per bounce; a BVH whose leaves are primitives already is walked well
         // enough by the general traversal until it is large (mesh + spheres, first member 485 spheres: 3 % slower split)
         if (items.size() < (prim_only ? 4096u : 64u)) return RT_OK;
         if (prim_only) { // its own 4-wide copy serves
-            const DNode& n = f.nodes[RT_REF_INDEX(first)];
-            bool ok = !(n.flags & 1u);
-            for (double v : n.bounds) ok = ok && std::isfinite(v);
-            if (ok) root_out = (int64_t)RT_REF_INDEX(first);
+            root_out = (int64_t)RT_REF_INDEX(first);
             return RT_OK;
         }
-        for (auto& it : items) {
-            if (box_has_nan(it.box)) return RT_OK;
-            for (double v : it.box.b) if (!std::isfinite(v)) return RT_OK;
-        }
-        const uint64_t count = bvh_node_count(items.size());
-        const uint64_t base = f.nodes.size();
-        if (base + count >= (1ull << 28)) return RT_OK;
-        f.nodes.resize(base + count);
-        f.wnodes.resize(base + count);
-        build_bvh(items, 0, items.size(), f.nodes.data() + base, f.wnodes.data() + base, base, 0, 0);
-        bvh_roots.push_back((uint32_t)base);
-        root_out = (int64_t)base;
+        root_out = build(items);
         return RT_OK;
     }
 
@@ -835,10 +848,15 @@ struct Flattener {
         if (hoisted_root >= 0 && f.fast_root == RT_REF_NONE && f.wnodes[(size_t)hoisted_root].qroot) {
             f.fast_root = make_ref(REF_QNODE, f.wnodes[(size_t)hoisted_root].qroot - 1);
             f.fast_stack = (uint32_t)need_q[(uint32_t)hoisted_root] + 1;
-            f.fast_partial = true;
-            const DList w = f.lists[RT_REF_INDEX(f.world)];
-            f.world_rest = make_ref(RT_REF_LIST, (uint32_t)f.lists.size());
-            f.lists.push_back(DList{w.first + 1u, w.count - 1u}); // shares the world's items
+            if (hoist_whole_world) { // as if the world were that one BVH
+                f.quant_inflation = quantise_qnodes();
+                if (f.quant_inflation > 1.25) f.cqnodes.clear();
+            } else {
+                f.fast_partial = true;
+                const DList w = f.lists[RT_REF_INDEX(f.world)];
+                f.world_rest = make_ref(RT_REF_LIST, (uint32_t)f.lists.size());
+                f.lists.push_back(DList{w.first + 1u, w.count - 1u}); // shares the world's items
+            }
         }
         need_node.assign(f.nodes.size(), -1);
         f.max_stack = (uint32_t)need(f.world) + 1;
