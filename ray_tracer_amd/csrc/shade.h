@@ -209,7 +209,9 @@ template <bool TEXTURES>
 RT_DEV bool shade_hit(const DScene& S, const HitRec& h, D3 ray_dir, Rng& g, D3& beta, D3& L, D3& next_d) {
     const DMaterial m = S.materials[h.mat];
     if (m.kind == RT_MAT_DIFFUSE_LIGHT) { // material.rs:237-256: emits on the front face, never scatters
-        if (h.front_face) L = L + beta * material_color<TEXTURES>(S, m, h.u, h.v, h.p);
+        // The back face emits black, and black still goes through the product: a path whose throughput is NaN
+        // or infinite (a light-pdf of 0/0) makes the sample NaN in the recursion, so it must here too.
+        L = L + beta * (h.front_face ? material_color<TEXTURES>(S, m, h.u, h.v, h.p) : d3(0.0, 0.0, 0.0));
         return false;
     }
     if (m.kind == RT_MAT_METAL) { // material.rs:135-158; skip_pdf branch camera.rs:276-295

@@ -25,7 +25,7 @@ class Mats:  # hands a different material to every primitive the scene generator
 def scaled(a, scale): return np.nan_to_num(a * scale, nan=0.0, posinf=1e6, neginf=0.0)
 
 
-def run(n_scenes, seed, textures=True):
+def run(n_scenes, seed, textures=True, only=None):
     g = np.random.default_rng(seed)
     failed, done = [], 0
     for k in range(n_scenes):
@@ -65,6 +65,7 @@ def run(n_scenes, seed, textures=True):
             print("scene", k, "rejected:", str(e)[:80]); continue
         c = cam.to_struct()
         rs = int(g.integers(1 << 30))
+        if only is not None and k != only: continue
         a = gpu.render(c, seed=rs)
         b = np.zeros_like(a)
         O.OracleScene(desc).render(c, seed=rs, accum=b, nthreads=8)
@@ -74,6 +75,21 @@ def run(n_scenes, seed, textures=True):
         close = float(np.isclose(sa, sb, rtol=1e-9, atol=1e-12).mean())
         # a path that crosses a decision boundary in the last place of a sine (device and glibc differ there) may end
         # elsewhere and change one pixel; anything systematic changes many
+        if only is not None:
+            fz.describe(world, 0)
+            bad = np.argwhere(~np.isclose(a, b, rtol=1e-9, atol=1e-12, equal_nan=True).all(axis=2))
+            print("depth", cam.max_depth, "differing pixels", len(bad))
+            for y, x in bad[:16]: print(" ", y, x, "gpu", a[y, x], "oracle", b[y, x])
+            from ray_tracer_amd import _ffi as F
+            d = O.camera_initialize(c)
+            cpu = O.OracleScene(desc)
+            for y, x in bad[:3]:  # which strata of the pixel differ
+                for st in range(d.sqrt_spp * d.sqrt_spp):
+                    w = F.rt_work(int(x), int(y), int(x) + 1, int(y) + 1, st, st + 1)
+                    ga = gpu.render(c, seed=rs, work=w)[y, x]
+                    ob = cpu.render(c, seed=rs, work=w, nthreads=1)[y, x]
+                    if not np.allclose(ga, ob, rtol=1e-9, atol=1e-12, equal_nan=True):
+                        print("   stratum", st, "gpu", ga, "oracle", ob)
         if close < 0.995:
             print("MISMATCH scene", k, "rmse", rmse, "close", close, "depth", cam.max_depth, "lights", lights is not None)
             failed.append(k)
@@ -83,5 +99,6 @@ def run(n_scenes, seed, textures=True):
 
 
 if __name__ == "__main__":
-    d, f = run(int(sys.argv[1]) if len(sys.argv) > 1 else 30, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    d, f = run(int(sys.argv[1]) if len(sys.argv) > 1 else 30, int(sys.argv[2]) if len(sys.argv) > 2 else 1,
+               only=int(sys.argv[3]) if len(sys.argv) > 3 else None)
     sys.exit(1 if f else 0)
