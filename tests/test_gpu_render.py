@@ -241,3 +241,24 @@ def test_nan_samples_land_on_the_same_pixels():
     assert np.isnan(b).any() and not np.isnan(b).all()
     assert np.array_equal(np.isnan(a), np.isnan(b))
     assert np.allclose(a, b, rtol=1e-9, atol=1e-12, equal_nan=True)
+
+
+def test_hoisted_traversal_agrees_with_the_general_kernel(monkeypatch):
+    """Worlds (or first world-list members) without instances and media are traced by the primitive-BVH kernel
+    over a BVH of their primitives; MI355RT_FAST_EXTEND=0 keeps the general traversal of the scene graph as it
+    was declared.  The closest hit does not depend on the grouping, so the frames agree (exact ties between
+    two primitives aside, which may pick the other material)."""
+    cases = [scenes.book2_final(seed=0, image_width=64, samples_per_pixel=4, max_depth=40),  # first member hoisted
+             scenes.mesh_and_spheres(image_width=96, samples_per_pixel=4, max_depth=20)]     # whole world hoisted
+    w1, l1, c1 = scenes.book1_final(seed=2)                                                   # one BVH: used as it is
+    c1.image_width, c1.samples_per_pixel, c1.max_depth = 96, 4, 30
+    cases.append((w1, l1, c1))
+    for world, lights, cam in cases:
+        g = rt.Scene(rt.SceneDesc.from_world(world, lights))
+        c = cam.to_struct()
+        monkeypatch.delenv("MI355RT_FAST_EXTEND", raising=False)
+        fast = g.render(c, seed=7).copy()
+        monkeypatch.setenv("MI355RT_FAST_EXTEND", "0")
+        general = g.render(c, seed=7).copy()
+        same = np.isclose(fast, general, rtol=1e-12, atol=1e-15, equal_nan=True).all(axis=2).mean()
+        assert same >= 0.999, same
