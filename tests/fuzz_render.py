@@ -28,6 +28,7 @@ def scaled(a, scale): return np.nan_to_num(a * scale, nan=0.0, posinf=1e6, negin
 def run(n_scenes, seed, textures=True, only=None):
     g = np.random.default_rng(seed)
     failed, done = [], 0
+    odd_pixels, odd_scenes, nan_odd = 0, [], 0  # pixels that differ at all, over the whole run
     for k in range(n_scenes):
         world = rt.HittableList()
         orig = fz.rand_prim
@@ -74,7 +75,7 @@ def run(n_scenes, seed, textures=True, only=None):
         rmse = float(np.sqrt(np.mean((sa - sb) ** 2)))
         close = float(np.isclose(sa, sb, rtol=1e-9, atol=1e-12).mean())
         # a path that crosses a decision boundary in the last place of a sine (device and glibc differ there) may end
-        # elsewhere and change one pixel; anything systematic changes many
+        # elsewhere and change one pixel; anything systematic changes many (1000 scenes of one run: no pixel at all)
         if only is not None:
             fz.describe(world, 0)
             bad = np.argwhere(~np.isclose(a, b, rtol=1e-9, atol=1e-12, equal_nan=True).all(axis=2))
@@ -90,10 +91,15 @@ def run(n_scenes, seed, textures=True, only=None):
                     ob = cpu.render(c, seed=rs, work=w, nthreads=1)[y, x]
                     if not np.allclose(ga, ob, rtol=1e-9, atol=1e-12, equal_nan=True):
                         print("   stratum", st, "gpu", ga, "oracle", ob)
-        if close < 0.995:
+        differ = ~np.isclose(a, b, rtol=1e-9, atol=1e-12, equal_nan=True).all(axis=2)
+        if differ.any():
+            odd_pixels += int(differ.sum()); odd_scenes.append(k)
+            nan_odd += int((np.isnan(a).any(axis=2) != np.isnan(b).any(axis=2)).sum())
+        if close < 0.995 or int(differ.sum()) > 3:
             print("MISMATCH scene", k, "rmse", rmse, "close", close, "depth", cam.max_depth, "lights", lights is not None)
             failed.append(k)
         done += 1
+    print("pixels that differ from the oracle's:", odd_pixels, "(NaN on one side only:", nan_odd, ") in scenes", odd_scenes)
     print("render fuzz ok:" if not failed else "render fuzz FAILED:", done, "scenes", failed)
     return done, failed
 
