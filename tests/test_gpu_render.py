@@ -42,7 +42,7 @@ def check(c, a, b, tol=RMSE_TOL):
     # most pixels agree to rounding; only paths that cross a decision boundary may differ
     close = np.isclose(sa, sb, rtol=1e-9, atol=1e-12).mean()
     assert rmse <= tol, (rmse, close)
-    assert close > 0.98, close
+    assert close >= 0.999, close  # measured on these frames: every pixel within 1e-9 relative, RMSE 1e-17 .. 1e-13
     assert sb.mean() > 1e-3, "oracle image is black: the test exercises nothing"
     return rmse
 
