@@ -24,6 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
+VALU_PEAK_TINSTR = 256 * 64 * 2.4e9 / 1e12  # lane-instructions per second, in units of 1e12
 NODE_BYTES, TRI_BYTES, RAY_BYTES, HIT_BYTES = 64, 72, 72, 48
 
 
@@ -147,6 +148,12 @@ def main() -> None:
                            "actual_bytes_per_ray": (16 * actual_nodes + 128 * actual_prims if args.mode == "ordered"
                                                     else 64 * actual_nodes + 128 * actual_prims) + RAY_BYTES + HIT_BYTES}
         out["roofline"]["achieved_actual"] = out["roofline"]["actual_bytes_per_ray"] * n / (avg_ms * 1e-3) / 1e9
+        # the second candidate roof: vector ALU lane-instructions (256 CUs x 64 lanes x 2.4 GHz), with the same
+        # reference-order visit counts: 45 per node visit (f64 slab test), 70 per triangle test, 40 per ray
+        instr_per_ray = 45.0 * nodes_per_ray + 70.0 * prims_per_ray + 40.0
+        valu_achieved = instr_per_ray * n / (avg_ms * 1e-3) / 1e12
+        out["roofline"]["valu"] = {"alg_lane_instr_per_ray": instr_per_ray, "achieved": valu_achieved, "peak": VALU_PEAK_TINSTR,
+                                   "unit": "T lane-instr/s", "frac": valu_achieved / VALU_PEAK_TINSTR}
         if out["roofline"]["traffic"]:
             # measured L2 <-> fabric bytes per launch (profiles/) over this run's kernel time: the binding roof
             out["roofline"]["traffic_gbs"] = out["roofline"]["traffic"] / (avg_ms * 1e-3) / 1e9
