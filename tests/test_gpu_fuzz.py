@@ -14,7 +14,11 @@ def test_random_scene_graphs_match_the_oracle():
 
 def test_random_scenes_render_like_the_oracle():
     """Random scene graphs with random materials (diffuse, checker, metal, glass, media), light lists of a quad and
-    sometimes a sphere, random cameras: at most one pixel in 200 may differ from the oracle beyond rounding."""
+    sometimes a sphere, random cameras: at most three pixels of a frame may differ from the oracle beyond rounding."""
     import fuzz_render
     done, failed = fuzz_render.run(60, 5)
     assert done >= 50 and not failed, failed
+    # seed 72, scene 314: paths that start inside a spherical light (light pdf 0/0) and end on a light's black
+    # back face; the oracle's samples are NaN there, and nine pixels once were finite on the device
+    done, failed = fuzz_render.run(315, 72, only=314)
+    assert done == 1 and not failed, failed
