@@ -259,6 +259,20 @@ int rt_closest_hit_device(rt_scene* scene, const rt_ray_batch* rays, uint64_t n,
                           rt_hit_batch* hits, uint64_t seed, uint32_t flags,
                           void* hip_stream);                                     /* device pointers */
 
+/* No counterpart in the reference.  For callers that cannot allocate device memory while they call (code
+ * under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): the same query as
+ * rt_closest_hit_device, same arguments and results, but the 4 bytes per ray of scratch that the general
+ * traversal keeps between its two kernels live in a fixed 64 MiB array inside the library's code object
+ * (one copy per GPU, held until the process ends) instead of a buffer grown with hipMalloc.
+ *   - n <= RT_NOALLOC_MAX_RAYS, else RT_E_TOO_LARGE;
+ *   - calls no hipMalloc / hipFree; the array's address is resolved per device by rt_scene_create;
+ *   - every call on one GPU shares that GPU's array: calls that overlap on one GPU (two streams, two
+ *     scenes, two threads) race on it and must be serialised by the caller. */
+#define RT_NOALLOC_MAX_RAYS (1ull << 24)
+int rt_closest_hit_device_noalloc(rt_scene* scene, const rt_ray_batch* rays, uint64_t n,
+                                  rt_hit_batch* hits, uint64_t seed, uint32_t flags,
+                                  void* hip_stream);                             /* device pointers */
+
 /* -------------------------------------------------------------------- render
  * Camera parameters: the public fields of camera.rs:15-27. */
 typedef struct rt_camera {

@@ -32,6 +32,7 @@ RT_REF_NONE = 0xFFFFFFFF
 RT_HIT_REFERENCE_ORDER = 0
 RT_HIT_ORDERED = 1
 RT_HIT_COUNTERS = 2
+RT_NOALLOC_MAX_RAYS = 1 << 24
 
 _d3 = C.c_double * 3
 
@@ -146,6 +147,7 @@ PROTOTYPES = {
     "rt_scene_object_bounds": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_double)]),
     "rt_closest_hit": (C.c_int, [C.c_void_p, C.POINTER(rt_ray_batch), C.c_uint64, C.POINTER(rt_hit_batch), C.c_uint64, C.c_uint32]),
     "rt_closest_hit_device": (C.c_int, [C.c_void_p, C.POINTER(rt_ray_batch), C.c_uint64, C.POINTER(rt_hit_batch), C.c_uint64, C.c_uint32, C.c_void_p]),
+    "rt_closest_hit_device_noalloc": (C.c_int, [C.c_void_p, C.POINTER(rt_ray_batch), C.c_uint64, C.POINTER(rt_hit_batch), C.c_uint64, C.c_uint32, C.c_void_p]),
     "rt_camera_initialize": (C.c_int, [C.POINTER(rt_camera), C.POINTER(rt_camera_derived)]),
     "rt_render": (C.c_int, [C.c_void_p, C.POINTER(rt_camera), C.c_uint64, C.POINTER(rt_work), C.c_void_p]),
     "rt_render_device": (C.c_int, [C.c_void_p, C.POINTER(rt_camera), C.c_uint64, C.POINTER(rt_work), C.c_void_p, C.c_void_p]),

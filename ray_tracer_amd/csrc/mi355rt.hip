@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -27,6 +28,13 @@
 #include "bvh_kernel.h"
 
 using namespace rt;
+
+// Scratch of rt_closest_hit_device_noalloc: the transform context of every hit of a batch, kept between the
+// traversal kernel and the record-completion kernel.  It lives in the code object, so every GPU the library
+// runs on holds its own 64 MiB copy until the process ends.  In host code the name is only a handle for
+// hipGetSymbolAddress: kernels and memsets take the per-device address kept in g_scratch_ptr.
+constexpr uint64_t NOALLOC_MAX_RAYS = 1ull << 24;
+static __device__ __align__(256) int32_t scratch[NOALLOC_MAX_RAYS];
 
 // ============================================================================ device code
 namespace {
@@ -550,6 +558,22 @@ int set_err(int code, const std::string& m) { g_err = m; return code; }
             return set_err(RT_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));           \
     } while (0)
 
+// Device address of `scratch` on every GPU the library has set up a scene on.  Each GPU holds its own copy of the
+// array at its own address, so the address is resolved once per device, with that device current.
+constexpr int NOALLOC_MAX_DEVICES = 64;
+int32_t* g_scratch_ptr[NOALLOC_MAX_DEVICES] = {};
+std::mutex g_scratch_mutex;
+
+int resolve_scratch(int device) {
+    if (device < 0 || device >= NOALLOC_MAX_DEVICES) return RT_OK; // such a device simply has no allocation-free entry point
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[device]) return RT_OK;
+    int32_t* ptr = nullptr;
+    HIP_TRY(hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(scratch)));
+    g_scratch_ptr[device] = ptr;
+    return RT_OK;
+}
+
 template <class T>
 int upload(rt_scene* s, const std::vector<T>& v, const T** out) {
     *out = nullptr;
@@ -670,6 +694,8 @@ int upload_scene(rt_scene* s) {
     HIP_TRY(hipEventCreate(&s->ev_hit1));
     HIP_TRY(hipEventCreate(&s->ev_r0));
     HIP_TRY(hipEventCreate(&s->ev_r1));
+    int rc2 = resolve_scratch(s->device); // the device is current here (rt_scene_create)
+    if (rc2) return rc2;
     return pick_grid(s);
 }
 
@@ -707,7 +733,10 @@ uint64_t max_paths_setting() {
     return 1ull << 27;
 }
 
-int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit_batch* hits, uint64_t seed, uint32_t flags, hipStream_t st) {
+// ctx_scratch: where the general kernels keep the transform context of every hit between traversal and record
+// completion (n words); nullptr = the scene's own buffer, grown with hipMalloc to the largest batch seen.
+int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit_batch* hits, uint64_t seed, uint32_t flags, hipStream_t st,
+                       int32_t* ctx_scratch = nullptr) {
     if (n == 0) return RT_OK;
     HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(unsigned long long), st)); // C_WORK
     HIP_TRY(hipMemsetAsync(s->d_counters + C_WORK_SLOTS, 0, WORK_SLOTS * WORK_STRIDE * sizeof(unsigned long long), st));
@@ -736,7 +765,7 @@ int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit
         s->counters.rays += n;
         return RT_OK;
     }
-    if (s->hit_ctx_cap < n) { // scratch between the traversal and the record-completion pass, grown to the largest batch seen
+    if (!ctx_scratch && s->hit_ctx_cap < n) { // scratch between the traversal and the record-completion pass, grown to the largest batch seen
         if (s->hit_ctx) (void)hipFree(s->hit_ctx);
         s->hit_ctx = nullptr; s->hit_ctx_cap = 0;
         void* p = nullptr;
@@ -744,6 +773,7 @@ int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit
         s->hit_ctx = static_cast<int32_t*>(p);
         s->hit_ctx_cap = n;
     }
+    int32_t* const hit_ctx = ctx_scratch ? ctx_scratch : s->hit_ctx;
     // ordered traversal of a world whose first member has a primitive BVH of its own: that member through the
     // primitive-BVH kernel, the rest through the general one, which starts from the first member's closest hit
     const bool split = ordered && !count && s->flat.fast_root != RT_REF_NONE && s->flat.fast_partial;
@@ -759,7 +789,7 @@ int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit
         HIP_TRY(hipMemsetAsync(s->d_counters + C_WORK_SLOTS, 0, WORK_SLOTS * WORK_STRIDE * sizeof(unsigned long long), st));
     }
     auto launch = [&](auto kernel) {
-        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(BLOCK), 0, st, s->dev, *rays, (unsigned long long)n, *hits, s->hit_ctx, (unsigned long long)seed, s->d_counters,
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(BLOCK), 0, st, s->dev, *rays, (unsigned long long)n, *hits, hit_ctx, (unsigned long long)seed, s->d_counters,
                            split ? 1 : 0);
     };
     if (s->flat.has_medium) {
@@ -773,7 +803,7 @@ int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit
         else if (ordered) launch(closest_hit_kernel<false, true, false>);
         else launch(closest_hit_kernel<false, false, false>);
     }
-    hipLaunchKernelGGL(finalize_hits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s->dev, *rays, (unsigned long long)n, *hits, (const int32_t*)s->hit_ctx);
+    hipLaunchKernelGGL(finalize_hits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s->dev, *rays, (unsigned long long)n, *hits, (const int32_t*)hit_ctx);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev_hit1, st));
     s->hit_timed = true;
@@ -1015,6 +1045,19 @@ int rt_closest_hit_device(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_
     if (n && (!rays->ox || !rays->oy || !rays->oz || !rays->dx || !rays->dy || !rays->dz || !hits->t || !hits->prim))
         return set_err(RT_E_INVALID, "rt_closest_hit_device: origin, direction, t and prim arrays are required");
     return launch_closest_hit(s, rays, n, hits, seed, flags, static_cast<hipStream_t>(hip_stream));
+}
+
+int rt_closest_hit_device_noalloc(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit_batch* hits, uint64_t seed, uint32_t flags, void* hip_stream) {
+    int rc = need_device(s);
+    if (rc) return rc;
+    if (!rays || !hits) return set_err(RT_E_INVALID, "rt_closest_hit_device_noalloc: null batch");
+    if (n && (!rays->ox || !rays->oy || !rays->oz || !rays->dx || !rays->dy || !rays->dz || !hits->t || !hits->prim))
+        return set_err(RT_E_INVALID, "rt_closest_hit_device_noalloc: origin, direction, t and prim arrays are required");
+    if (n > NOALLOC_MAX_RAYS)
+        return set_err(RT_E_TOO_LARGE, "rt_closest_hit_device_noalloc: at most 16777216 (2^24) rays per call; split the batch or use rt_closest_hit_device");
+    int32_t* const ptr = (s->device >= 0 && s->device < NOALLOC_MAX_DEVICES) ? g_scratch_ptr[s->device] : nullptr;
+    if (!ptr) return set_err(RT_E_HIP, "rt_closest_hit_device_noalloc: the scratch array of this device was not resolved at scene creation");
+    return launch_closest_hit(s, rays, n, hits, seed, flags, static_cast<hipStream_t>(hip_stream), ptr);
 }
 
 int rt_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit_batch* hits, uint64_t seed, uint32_t flags) {

@@ -302,13 +302,15 @@ class Scene:
         return hits
 
     def closest_hit_device(self, rays: Dict[str, "object"], hits: Dict[str, "object"], n: int, seed: int = 0,
-                           flags: int = 0, stream: int = 0) -> None:
+                           flags: int = 0, stream: int = 0, noalloc: bool = False) -> None:
         """Same query on arrays already resident in HBM: `rays` / `hits` map field names to objects
-        with a `data_ptr()` (torch tensors); absent optional fields are passed as NULL."""
+        with a `data_ptr()` (torch tensors); absent optional fields are passed as NULL.
+        `noalloc` takes the entry point that allocates nothing (at most RT_NOALLOC_MAX_RAYS rays)."""
         rb = F.rt_ray_batch(*[rays[f].data_ptr() if f in rays else None
                               for f in ("ox", "oy", "oz", "dx", "dy", "dz", "time", "tmin", "tmax")])
         hb = F.rt_hit_batch(*[hits[f].data_ptr() if f in hits else None for f in HIT_FIELDS])
-        F.check(F.lib.rt_closest_hit_device(self._h, C.byref(rb), n, C.byref(hb), seed, flags, C.c_void_p(stream)))
+        fn = F.lib.rt_closest_hit_device_noalloc if noalloc else F.lib.rt_closest_hit_device
+        F.check(fn(self._h, C.byref(rb), n, C.byref(hb), seed, flags, C.c_void_p(stream)))
 
     # ------------------------------------------------------------------- render
     def render(self, cam: F.rt_camera, seed: int = 0, work: Optional[F.rt_work] = None,

@@ -1,0 +1,87 @@
+"""rt_closest_hit_device_noalloc (the entry point that allocates nothing: its per-ray scratch is a fixed
+array inside the library's code object) against rt_closest_hit_device, through the C ABI, on device
+buffers.  Bar: every output array identical bit for bit.  Two calls in a row on each scene, the second
+with a smaller batch, so that stale scratch contents of the first call would show.
+
+Scenes: the Cornell box (transform chains: the scratch holds non-zero contexts), the Book-2 final scene
+(constant media, a hoisted first member: the split traversal), and a triangle mesh (the primitive-BVH
+kernel, which needs no scratch), in both traversal orders."""
+import numpy as np
+import pytest
+
+import ray_tracer_amd as rt
+from ray_tracer_amd import _ffi as F
+from ray_tracer_amd import scenes
+from ray_tracer_amd.scene import HIT_FIELDS
+
+pytestmark = pytest.mark.gpu
+
+_TORCH_DT = {"prim": "int32", "front_face": "uint8", "mat": "int32"}
+
+
+def _device_rays(torch, dev, o, d, tm):
+    rays = {}
+    for k, nm in enumerate(("ox", "oy", "oz")):
+        rays[nm] = torch.from_numpy(np.ascontiguousarray(o[:, k])).to(dev)
+    for k, nm in enumerate(("dx", "dy", "dz")):
+        rays[nm] = torch.from_numpy(np.ascontiguousarray(d[:, k])).to(dev)
+    rays["time"] = torch.from_numpy(np.ascontiguousarray(tm)).to(dev)
+    return rays
+
+
+def _query(torch, dev, gpu, rays, n, flags, noalloc):
+    hits = {f: torch.full((n,), 7, dtype=getattr(torch, _TORCH_DT.get(f, "float64")), device=dev) for f in HIT_FIELDS}
+    r = {k: v[:n].contiguous() for k, v in rays.items()}
+    gpu.closest_hit_device(r, hits, n, seed=5, flags=flags, stream=torch.cuda.current_stream().cuda_stream, noalloc=noalloc)
+    torch.cuda.synchronize()
+    return {f: hits[f].cpu().numpy() for f in HIT_FIELDS}
+
+
+def _same(a, b):
+    for f in HIT_FIELDS:
+        x, y = a[f], b[f]
+        if x.dtype == np.float64:
+            x, y = x.view(np.uint64), y.view(np.uint64)  # bit for bit, NaN included
+        assert np.array_equal(x, y), f
+
+
+def test_noalloc_entry_point_matches_allocating_one():
+    import torch
+    assert torch.cuda.is_available()
+    dev = torch.device("cuda", 0)
+    m = rt.Lambertian(rt.Color(.5, .5, .5))
+    cases = []
+    world, lights, _ = scenes.cornell_box()
+    cases.append((rt.SceneDesc.from_world(world, lights), [1, 554, 1, 554, 1, 554]))
+    world, lights, _ = scenes.book2_final(seed=0)
+    cases.append((rt.SceneDesc.from_world(world, lights), [-200, 600, 0, 560, -200, 600]))
+    cases.append((rt.SceneDesc.from_world(rt.Mesh(scenes.triangle_soup(20000, seed=13, edge=0.05), m)), [0, 1, 0, 1, 0, 1]))
+    n_first, n_second = 100000, 33333
+    for desc, box in cases:
+        gpu = rt.Scene(desc)
+        o, d, tm = scenes.incoherent_rays(n_first, box, seed=41)
+        rays = _device_rays(torch, dev, o, d, tm)
+        for flags in (F.RT_HIT_REFERENCE_ORDER, F.RT_HIT_ORDERED):
+            want_big = _query(torch, dev, gpu, rays, n_first, flags, noalloc=False)
+            want_small = _query(torch, dev, gpu, rays, n_second, flags, noalloc=False)
+            assert (want_big["prim"] != F.RT_REF_NONE).sum() > n_first // 10
+            got_big = _query(torch, dev, gpu, rays, n_first, flags, noalloc=True)      # first call
+            got_small = _query(torch, dev, gpu, rays, n_second, flags, noalloc=True)   # second call, smaller input
+            _same(got_big, want_big)
+            _same(got_small, want_small)
+        gpu.close()
+
+
+def test_noalloc_entry_point_rejects_oversized_batches():
+    import torch
+    assert torch.cuda.is_available()
+    m = rt.Lambertian(rt.Color(.5, .5, .5))
+    gpu = rt.Scene(rt.HittableList.with_object(rt.Sphere(rt.Point3(0, 0, -1), 0.5, m)))
+    one = torch.zeros(8, dtype=torch.float64, device="cuda:0")
+    rb = F.rt_ray_batch(*([one.data_ptr()] * 6 + [None] * 3))
+    prim = torch.zeros(8, dtype=torch.int32, device="cuda:0")
+    hb = F.rt_hit_batch(one.data_ptr(), prim.data_ptr(), *([None] * 10))
+    import ctypes as C
+    rc = F.lib.rt_closest_hit_device_noalloc(gpu.handle, C.byref(rb), F.RT_NOALLOC_MAX_RAYS + 1, C.byref(hb), 0, 0, None)
+    assert rc == F.RT_E_TOO_LARGE and b"2^24" in F.lib.rt_last_error()
+    gpu.close()
