@@ -339,8 +339,10 @@ typedef struct rt_counters {
     uint64_t paths;          /* camera samples started by rt_render* */
     uint64_t render_rays;    /* world.hit queries issued by rt_render* (camera.rs:258 calls) */
     uint64_t extend_launches;
-    double   ms_last_closest_hit; /* device time of the last rt_closest_hit* kernel, HIP events */
+    double   ms_last_closest_hit; /* device time of the last rt_closest_hit* call: reorder pass, traversal, record completion (HIP events on the call's stream) */
     double   ms_last_render;      /* device time of the last rt_render* call */
+    double   ms_last_traversal;   /* of that closest-hit call, the traversal kernel alone */
+    double   ms_last_reorder;     /* of that closest-hit call, the binning pass in front of the traversal (0 when the batch was not reordered) */
 } rt_counters;
 
 int rt_get_counters(rt_scene* scene, rt_counters* out);

@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmi355rt.so")
+# MI355RT_LIB: load a measurement build of the same library instead (ablations, phase timers); never a fallback
+LIB_PATH = os.environ.get("MI355RT_LIB") or os.path.join(_HERE, "libmi355rt.so")
 
 RT_OK = 0
 RT_E_INVALID = -1
@@ -133,7 +134,7 @@ class rt_work(C.Structure):
 class rt_counters(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("node_visits", C.c_uint64), ("prim_tests", C.c_uint64), ("paths", C.c_uint64),
                 ("render_rays", C.c_uint64), ("extend_launches", C.c_uint64), ("ms_last_closest_hit", C.c_double),
-                ("ms_last_render", C.c_double)]
+                ("ms_last_render", C.c_double), ("ms_last_traversal", C.c_double), ("ms_last_reorder", C.c_double)]
 
 
 # Every symbol include/mi355rt.h declares, with its prototype.

@@ -22,6 +22,7 @@
 #define RT_BVH_KERNEL_H
 
 #include "traverse.h"
+#include "reorder.h"
 
 namespace rt {
 
@@ -29,6 +30,10 @@ constexpr int FAST_BLOCK = 256;
 constexpr int REFILL_THRESHOLD = 40; // refill when fewer lanes than this are still traversing
 constexpr int POP_TRIPS = 2;         // stack entries a lane may take (and discard) per iteration
 constexpr int LEAF_VOTE = 24;        // lanes that must stand on a primitive before the wave runs the intersector
+// Reordered batches (reorder.h): a refill is eight loads from one line, so the wave tops itself up much earlier; and
+// with the fabric no longer the bound, running the intersector with fewer lanes costs less than holding lanes back.
+constexpr int PREP_REFILL_THRESHOLD = 56;
+constexpr int PREP_LEAF_VOTE = 16;
 
 struct RayQueue {              // optional indirection: ray i of the launch is path queue[i]
     const uint32_t* queue;     // nullptr: identity
@@ -87,13 +92,15 @@ RT_DEV float ubyte_f32(uint32_t w, int byte) { return (float)((w >> (8 * byte)) 
 // RS = element stride of the batch arrays: 1 for the structure-of-arrays batches of the C ABI.  The
 // renderer hands in strided views of its 128-byte path records instead of copying rays out of them
 // (RS = doubles per record; out_t shares that stride, out_prim counts 32-bit words: 2 * RS).
-template <int PRIM, bool COUNT, bool QUANT, int RS>
+// PREP: the batch is the array `prep` of prepared records in bin order (reorder.h) instead of `rays`; a record
+// carries the ray's index in the caller's batch, where the result goes.
+template <int PRIM, bool COUNT, bool QUANT, int RS, bool PREP>
 __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, uint32_t root, rt_ray_batch rays,
                                                                        unsigned long long n_in, RayQueue rq, uint32_t opt, double tmin_default,
                                                                        float scene_extent, double* out_t, uint32_t* out_prim,
                                                                        unsigned long long* work_counter,
                                                                        unsigned long long* stat_counters, uint2* spill, int refill_threshold,
-                                                                       int leaf_vote, int chunk_in, int pop_trips) {
+                                                                       int leaf_vote, int chunk_in, int pop_trips, const PRay* prep) {
     constexpr unsigned long long OUT_T_STRIDE = RS, OUT_PRIM_STRIDE = RS == 1 ? 1 : 2 * RS;
     __shared__ uint2 s_fast_stack[LDS_STACK * FAST_BLOCK];
     LaneStack st;
@@ -164,7 +171,23 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, 
                 }
                 if (!active) {
                     const unsigned long long qi = wave_next + (unsigned long long)__popcll(idle & lane_below);
-                    if (qi < wave_end) {
+                    if (PREP) {
+                        if (qi < wave_end) {
+                            const PRay p = prep[qi]; // one line, eight 16-byte loads
+                            r.ox = p.o[0]; r.oy = p.o[1]; r.oz = p.o[2];
+                            r.dx = p.d[0]; r.dy = p.d[1]; r.dz = p.d[2];
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) { q.inv[k] = p.inv[k]; q.cn[k] = p.cn[k]; q.cf[k] = p.cf[k]; q.neg[k] = (p.neg >> k) & 1u; }
+                            time = p.time; tmin = p.tmin; best_t = p.tmax;
+                            tmin32 = p.tmin32; best32 = p.tmax32;
+                            best_ref = RT_REF_NONE;
+                            ray_slot = p.idx;
+                            cur = root;
+                            RT_STACK_RESET(st);
+                            active = true;
+                            pop = false;
+                        }
+                    } else if (qi < wave_end) {
                         const unsigned long long i = rq.queue ? (unsigned long long)rq.queue[qi] : qi;
                         const unsigned long long ri = i * (unsigned long long)RS;
                         r.ox = rays.ox[ri]; r.oy = rays.oy[ri]; r.oz = rays.oz[ri];

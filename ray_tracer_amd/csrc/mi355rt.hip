@@ -517,6 +517,20 @@ __global__ __launch_bounds__(BLOCK) void accumulate_kernel(PathState ps, BatchGe
 } // namespace
 
 // ============================================================================ host code
+// Measurement switches, read from the environment ONCE, when a scene is created (never per launch).
+struct Tuning {
+    int refill = REFILL_THRESHOLD, vote = LEAF_VOTE, chunk = 0, pop_trips = POP_TRIPS; // primitive-BVH kernel scheduling
+    int prep_refill = PREP_REFILL_THRESHOLD, prep_vote = PREP_LEAF_VOTE;               // the same for reordered batches
+    bool quant = true;           // MI355RT_QUANT=0: keep the f32 4-wide nodes
+    bool fast_extend = true;     // MI355RT_FAST_EXTEND=0: the renderer keeps the general traversal
+    bool shade_textures = false; // MI355RT_SHADE_TEXTURES=1: always the full shading kernel
+    bool reorder = true;         // MI355RT_REORDER=0: no binning pass in front of large closest-hit batches
+    bool debug = false;          // MI355RT_DEBUG: diagnostics on stderr
+    uint64_t reorder_min = 1ull << 18; // smallest batch that is binned
+    uint64_t tail_paths = 1ull << 16;
+    uint64_t max_paths = 1ull << 27;
+};
+
 struct rt_scene {
     FlatScene flat;
     DScene dev{};
@@ -543,6 +557,17 @@ struct rt_scene {
     PathState ps{};
     uint64_t ws_paths = 0;
     std::vector<void*> ws_allocs;
+    // reorder pass in front of the primitive-BVH kernel (reorder.h): prepared records in bin order, the bin of every
+    // ray, histogram and bin cursors; grown to the largest batch seen
+    PRay* prep = nullptr;
+    uint16_t* prep_bins = nullptr;
+    uint32_t* prep_hist = nullptr;   // REORDER_BINS words, zero between batches
+    uint32_t* prep_cursor = nullptr; // REORDER_BINS words
+    uint64_t prep_cap = 0;
+    ReorderGrid grid{};
+    hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr; // around the traversal kernel of the last closest-hit call
+    bool hit_reordered = false;
+    Tuning tune;
 };
 
 namespace {
@@ -588,22 +613,51 @@ int upload(rt_scene* s, const std::vector<T>& v, const T** out) {
 }
 
 using FastKernel = void (*)(DScene, uint32_t, rt_ray_batch, unsigned long long, RayQueue, uint32_t, double, float, double*, uint32_t*,
-                            unsigned long long*, unsigned long long*, uint2*, int, int, int, int);
-template <bool COUNT, bool QUANT, int RS> FastKernel fast_kernel_for(int prim) {
-    if (prim == (int)RT_REF_TRI) return bvh4_closest_hit_kernel<RT_REF_TRI, COUNT, QUANT, RS>;
-    if (prim == (int)RT_REF_SPHERE) return bvh4_closest_hit_kernel<RT_REF_SPHERE, COUNT, QUANT, RS>;
-    return bvh4_closest_hit_kernel<0, COUNT, QUANT, RS>;
+                            unsigned long long*, unsigned long long*, uint2*, int, int, int, int, const PRay*);
+template <bool COUNT, bool QUANT, int RS, bool PREP> FastKernel fast_kernel_for(int prim) {
+    if (prim == (int)RT_REF_TRI) return bvh4_closest_hit_kernel<RT_REF_TRI, COUNT, QUANT, RS, PREP>;
+    if (prim == (int)RT_REF_SPHERE) return bvh4_closest_hit_kernel<RT_REF_SPHERE, COUNT, QUANT, RS, PREP>;
+    return bvh4_closest_hit_kernel<0, COUNT, QUANT, RS, PREP>;
 }
 FastKernel fast_kernel(int prim, bool count, bool quant) { // structure-of-arrays batches of the C ABI
-    if (quant) return count ? fast_kernel_for<true, true, 1>(prim) : fast_kernel_for<false, true, 1>(prim);
-    return count ? fast_kernel_for<true, false, 1>(prim) : fast_kernel_for<false, false, 1>(prim);
+    if (quant) return count ? fast_kernel_for<true, true, 1, false>(prim) : fast_kernel_for<false, true, 1, false>(prim);
+    return count ? fast_kernel_for<true, false, 1, false>(prim) : fast_kernel_for<false, false, 1, false>(prim);
+}
+FastKernel fast_kernel_prepared(int prim, bool count, bool quant) { // batches binned and prepared by the reorder pass
+    if (quant) return count ? fast_kernel_for<true, true, 1, true>(prim) : fast_kernel_for<false, true, 1, true>(prim);
+    return count ? fast_kernel_for<true, false, 1, true>(prim) : fast_kernel_for<false, false, 1, true>(prim);
 }
 FastKernel fast_kernel_paths(int prim, bool quant) { // strided views of the renderer's path records
-    return quant ? fast_kernel_for<false, true, (int)PATH_DOUBLES>(prim) : fast_kernel_for<false, false, (int)PATH_DOUBLES>(prim);
+    return quant ? fast_kernel_for<false, true, (int)PATH_DOUBLES, false>(prim) : fast_kernel_for<false, false, (int)PATH_DOUBLES, false>(prim);
 }
 int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
     return e ? atoi(e) : dflt;
+}
+Tuning read_tuning() {
+    Tuning t;
+    t.refill = env_int("MI355RT_REFILL", t.refill);
+    t.vote = env_int("MI355RT_VOTE", t.vote);
+    t.chunk = env_int("MI355RT_CHUNK", t.chunk);
+    t.pop_trips = env_int("MI355RT_POP_TRIPS", t.pop_trips);
+    t.prep_refill = env_int("MI355RT_PREP_REFILL", t.prep_refill);
+    t.prep_vote = env_int("MI355RT_PREP_VOTE", t.prep_vote);
+    t.quant = env_int("MI355RT_QUANT", 1) != 0;
+    t.fast_extend = env_int("MI355RT_FAST_EXTEND", 1) != 0;
+    t.shade_textures = env_int("MI355RT_SHADE_TEXTURES", 0) != 0;
+    t.reorder = env_int("MI355RT_REORDER", 1) != 0;
+    t.debug = getenv("MI355RT_DEBUG") != nullptr;
+    t.reorder_min = (uint64_t)std::max(1, env_int("MI355RT_REORDER_MIN", (int)t.reorder_min));
+    t.tail_paths = (uint64_t)std::max(0, env_int("MI355RT_TAIL_PATHS", TAIL_PATHS));
+    // Paths per render batch.  17 GB of path records and queues when a frame is that large (the workspace is sized
+    // to the frame, up to this cap): every bounce is a launch whose tail runs at one ray's latency, so few large
+    // batches beat many small ones (Cornell 600x600x100: 798 / 868 / 934 M samples/s at 2^24 / 2^25 / 2^26).
+    // Path ids and queue slots are 32-bit, so the cap stays below 2^31.
+    if (const char* e = getenv("MI355RT_MAX_PATHS")) {
+        const long long v = atoll(e);
+        if (v >= 1024) t.max_paths = (uint64_t)std::min<long long>(v, 1ll << 31);
+    }
+    return t;
 }
 int pick_grid(rt_scene* s) {
     hipDeviceProp_t prop;
@@ -631,7 +685,7 @@ int pick_grid(rt_scene* s) {
         s->fast_prim = (tr && !sp && !qd) ? (int)RT_REF_TRI : ((sp && !tr && !qd) ? (int)RT_REF_SPHERE : 0);
         int fast_per_cu = 0;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fast_per_cu, fast_kernel(s->fast_prim, false, s->fast_quant), FAST_BLOCK, 0));
-        if (getenv("MI355RT_DEBUG"))
+        if (s->tune.debug)
             fprintf(stderr, "[mi355rt] primitive-BVH kernel: 8-bit nodes=%d (inflation %.3f) blocks/CU=%d\n", (int)s->fast_quant, s->flat.quant_inflation, fast_per_cu);
         s->fast_grid_blocks = prop.multiProcessorCount * std::max(1, fast_per_cu);
         {
@@ -666,7 +720,7 @@ int upload_scene(rt_scene* s) {
     // the f32 4-wide nodes always go to the device (the general kernel's ordered traversal enters them at every BVH
     // root); the 8-bit copy only when the primitive-BVH kernel will read it
     // (MI355RT_QUANT=0 keeps that kernel on the f32 nodes even when the 8-bit ones were accepted, for A/B measurements)
-    s->fast_quant = !f.cqnodes.empty() && env_int("MI355RT_QUANT", 1) != 0;
+    s->fast_quant = !f.cqnodes.empty() && s->tune.quant;
     const std::vector<CQNode> no_cqnodes;
     if ((rc = upload(s, f.qnodes, &d.qnodes))) return rc;
     if ((rc = upload(s, s->fast_quant ? f.cqnodes : no_cqnodes, &d.cqnodes))) return rc;
@@ -694,6 +748,17 @@ int upload_scene(rt_scene* s) {
     HIP_TRY(hipEventCreate(&s->ev_hit1));
     HIP_TRY(hipEventCreate(&s->ev_r0));
     HIP_TRY(hipEventCreate(&s->ev_r1));
+    HIP_TRY(hipEventCreate(&s->ev_k0));
+    HIP_TRY(hipEventCreate(&s->ev_k1));
+    {   // grid of the reorder pass: 16 cells per axis over the world's box (a degenerate or unbounded axis gets one cell)
+        const double* wb = s->flat.world_bounds.b;
+        for (int k = 0; k < 3; ++k) {
+            const double lo = wb[2 * k], ext = wb[2 * k + 1] - wb[2 * k];
+            const bool ok = std::isfinite(lo) && std::isfinite(ext) && ext > 0.0;
+            s->grid.lo[k] = ok ? lo : 0.0;
+            s->grid.scale[k] = ok ? (double)(1 << REORDER_BITS) / ext : 0.0;
+        }
+    }
     int rc2 = resolve_scratch(s->device); // the device is current here (rt_scene_create)
     if (rc2) return rc2;
     return pick_grid(s);
@@ -723,14 +788,24 @@ int ensure_workspace(rt_scene* s, uint64_t paths) {
     return RT_OK;
 }
 
-uint64_t max_paths_setting() {
-    const char* e = getenv("MI355RT_MAX_PATHS");
-    if (e) { long long v = atoll(e); if (v >= 1024) return (uint64_t)v; }
-    // 17 GB of path records and queues when a frame is that large (the workspace is sized to the frame, up to
-    // this cap): every bounce is a launch whose tail runs at one ray's latency, so few large batches beat many
-    // small ones.  Cornell 600x600x100: 798 / 868 / 934 M samples/s at 2^24 / 2^25 / 2^26; 625 spp: 1049 / 1088 /
-    // 1113 M at 2^26 / 2^27 / 2^28.
-    return 1ull << 27;
+int ensure_reorder_scratch(rt_scene* s, uint64_t n) {
+    if (s->prep_cap >= n) return RT_OK;
+    if (s->prep) (void)hipFree(s->prep);
+    if (s->prep_bins) (void)hipFree(s->prep_bins);
+    s->prep = nullptr; s->prep_bins = nullptr; s->prep_cap = 0;
+    void* p = nullptr;
+    if (!s->prep_hist) {
+        HIP_TRY(hipMalloc(&p, 2 * REORDER_BINS * sizeof(uint32_t)));
+        s->prep_hist = static_cast<uint32_t*>(p);
+        s->prep_cursor = s->prep_hist + REORDER_BINS;
+        HIP_TRY(hipMemset(p, 0, 2 * REORDER_BINS * sizeof(uint32_t)));
+    }
+    HIP_TRY(hipMalloc(&p, n * sizeof(PRay)));
+    s->prep = static_cast<PRay*>(p);
+    HIP_TRY(hipMalloc(&p, n * sizeof(uint16_t)));
+    s->prep_bins = static_cast<uint16_t*>(p);
+    s->prep_cap = n;
+    return RT_OK;
 }
 
 // ctx_scratch: where the general kernels keep the transform context of every hit between traversal and record
@@ -744,24 +819,38 @@ int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit
     int blocks = (int)std::min<uint64_t>((uint64_t)s->grid_blocks, (waves + (BLOCK / 64) - 1) / (BLOCK / 64));
     HIP_TRY(hipEventRecord(s->ev_hit0, st));
     const bool count = flags & RT_HIT_COUNTERS, ordered = flags & RT_HIT_ORDERED;
+    const Tuning& tn = s->tune;
     if (ordered && s->flat.fast_root != RT_REF_NONE && !s->flat.fast_partial) {
         // the world is one BVH over primitives: dedicated traversal kernel + one pass that completes the records
         int fblocks = (int)std::min<uint64_t>((uint64_t)s->fast_grid_blocks, (waves + (FAST_BLOCK / 64) - 1) / (FAST_BLOCK / 64));
         RayQueue rq{nullptr, nullptr};
         const uint32_t opt = (rays->time ? 1u : 0u) | (rays->tmin ? 2u : 0u) | (rays->tmax ? 4u : 0u);
-        auto flaunch = [&](auto kernel) {
-            hipLaunchKernelGGL(kernel, dim3(fblocks), dim3(FAST_BLOCK), 0, st, s->dev, s->flat.fast_root, *rays, (unsigned long long)n, rq, opt, 0.001,
-                               s->fast_extent, hits->t, hits->prim, s->d_counters + C_WORK_SLOTS, s->d_counters + C_NODES, s->fast_spill,
-                               env_int("MI355RT_REFILL", REFILL_THRESHOLD), env_int("MI355RT_VOTE", LEAF_VOTE), env_int("MI355RT_CHUNK", 0),
-                               env_int("MI355RT_POP_TRIPS", POP_TRIPS));
-        };
-        flaunch(fast_kernel(s->fast_prim, count, s->fast_quant));
+        // large batches are binned by origin cell and prepared first (reorder.h); the allocation-free entry point
+        // (ctx_scratch given) never grows the pass's scratch and so goes without it
+        const bool reorder = tn.reorder && !ctx_scratch && n >= tn.reorder_min && n <= 0xFFFFFFFFull;
+        if (reorder) {
+            int rc = ensure_reorder_scratch(s, n);
+            if (rc) return rc;
+            const int cblocks = (int)std::min<uint64_t>(2048, (n + REORDER_BLOCK - 1) / REORDER_BLOCK);
+            hipLaunchKernelGGL(reorder_count_kernel, dim3(cblocks), dim3(REORDER_BLOCK), 0, st, *rays, (unsigned long long)n, s->grid, s->prep_bins, s->prep_hist);
+            hipLaunchKernelGGL(reorder_scan_kernel, dim3(1), dim3(1024), 0, st, s->prep_hist, s->prep_cursor);
+            hipLaunchKernelGGL(reorder_scatter_kernel, dim3((unsigned)((n + REORDER_TILE - 1) / REORDER_TILE)), dim3(SCATTER_BLOCK), 0, st, *rays,
+                               (unsigned long long)n, opt, 0.001, s->fast_extent, (const uint16_t*)s->prep_bins, s->prep_cursor, s->prep);
+            HIP_TRY(hipGetLastError());
+        }
+        HIP_TRY(hipEventRecord(s->ev_k0, st));
+        hipLaunchKernelGGL(reorder ? fast_kernel_prepared(s->fast_prim, count, s->fast_quant) : fast_kernel(s->fast_prim, count, s->fast_quant),
+                           dim3(fblocks), dim3(FAST_BLOCK), 0, st, s->dev, s->flat.fast_root, *rays, (unsigned long long)n, rq, opt, 0.001,
+                           s->fast_extent, hits->t, hits->prim, s->d_counters + C_WORK_SLOTS, s->d_counters + C_NODES, s->fast_spill,
+                           reorder ? tn.prep_refill : tn.refill, reorder ? tn.prep_vote : tn.vote, tn.chunk, tn.pop_trips, (const PRay*)s->prep);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(s->ev_hit1, st));
+        HIP_TRY(hipEventRecord(s->ev_k1, st));
         if (hits->u || hits->v || hits->front_face || hits->mat || hits->nx || hits->ny || hits->nz || hits->px || hits->py || hits->pz)
             hipLaunchKernelGGL(finalize_hits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s->dev, *rays, (unsigned long long)n, *hits, (const int32_t*)nullptr);
         HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(s->ev_hit1, st)); // the whole call: reorder pass, traversal, record completion
         s->hit_timed = true;
+        s->hit_reordered = reorder;
         s->counters.rays += n;
         return RT_OK;
     }
@@ -783,11 +872,11 @@ int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit
         const uint32_t opt = (rays->time ? 1u : 0u) | (rays->tmin ? 2u : 0u) | (rays->tmax ? 4u : 0u);
         hipLaunchKernelGGL(fast_kernel(s->fast_prim, false, s->fast_quant), dim3(fblocks), dim3(FAST_BLOCK), 0, st, s->dev, s->flat.fast_root, *rays,
                            (unsigned long long)n, rq, opt, 0.001, s->fast_extent, hits->t, hits->prim, s->d_counters + C_WORK_SLOTS, s->d_counters + C_NODES,
-                           s->fast_spill, env_int("MI355RT_REFILL", REFILL_THRESHOLD), env_int("MI355RT_VOTE", LEAF_VOTE), env_int("MI355RT_CHUNK", 0),
-                           env_int("MI355RT_POP_TRIPS", POP_TRIPS));
+                           s->fast_spill, tn.refill, tn.vote, tn.chunk, tn.pop_trips, (const PRay*)nullptr);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemsetAsync(s->d_counters + C_WORK_SLOTS, 0, WORK_SLOTS * WORK_STRIDE * sizeof(unsigned long long), st));
     }
+    HIP_TRY(hipEventRecord(s->ev_k0, st));
     auto launch = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3(blocks), dim3(BLOCK), 0, st, s->dev, *rays, (unsigned long long)n, *hits, hit_ctx, (unsigned long long)seed, s->d_counters,
                            split ? 1 : 0);
@@ -803,10 +892,12 @@ int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit
         else if (ordered) launch(closest_hit_kernel<false, true, false>);
         else launch(closest_hit_kernel<false, false, false>);
     }
+    HIP_TRY(hipEventRecord(s->ev_k1, st));
     hipLaunchKernelGGL(finalize_hits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s->dev, *rays, (unsigned long long)n, *hits, (const int32_t*)hit_ctx);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev_hit1, st));
     s->hit_timed = true;
+    s->hit_reordered = false;
     s->counters.rays += n;
     return RT_OK;
 }
@@ -830,7 +921,7 @@ int render_impl(rt_scene* s, const rt_camera* cam, uint64_t seed, const rt_work*
         return set_err(RT_E_INVALID, "render: sample range outside [0, sqrt_spp^2]");
     const int32_t tw = w.x1 - w.x0;
     if (tw == 0 || w.y0 == w.y1 || w.sample_begin == w.sample_end) return RT_OK;
-    const uint64_t cap = max_paths_setting();
+    const uint64_t cap = s->tune.max_paths;
     if ((uint64_t)tw > cap) return set_err(RT_E_TOO_LARGE, "render: one image row exceeds the path workspace");
     const int32_t rows_per_tile = (int32_t)std::min<uint64_t>((uint64_t)(w.y1 - w.y0), cap / (uint64_t)tw);
     const uint64_t tile_pix_max = (uint64_t)rows_per_tile * (uint64_t)tw;
@@ -852,11 +943,10 @@ int render_impl(rt_scene* s, const rt_camera* cam, uint64_t seed, const rt_work*
             int qsel = 0;
             uint64_t live = bg.npaths;
             // MI355RT_FAST_EXTEND=0 keeps the general traversal for BVH-only worlds (A/B measurements)
-            const bool fast_extend = s->flat.fast_root != RT_REF_NONE && env_int("MI355RT_FAST_EXTEND", 1) != 0;
-            const bool has_tex = s->flat.has_textures || env_int("MI355RT_SHADE_TEXTURES", 0); // the switch forces the full shading code (A/B tests)
-            const uint64_t tail_paths = (uint64_t)env_int("MI355RT_TAIL_PATHS", TAIL_PATHS);
-            const int k_refill = env_int("MI355RT_REFILL", REFILL_THRESHOLD), k_vote = env_int("MI355RT_VOTE", LEAF_VOTE); // read once per batch,
-            const int k_chunk = env_int("MI355RT_CHUNK", 0), k_pop = env_int("MI355RT_POP_TRIPS", POP_TRIPS);                // not once per bounce
+            const bool fast_extend = s->flat.fast_root != RT_REF_NONE && s->tune.fast_extend;
+            const bool has_tex = s->flat.has_textures || s->tune.shade_textures; // the switch forces the full shading code (A/B tests)
+            const uint64_t tail_paths = s->tune.tail_paths;
+            const int k_refill = s->tune.refill, k_vote = s->tune.vote, k_chunk = s->tune.chunk, k_pop = s->tune.pop_trips;
             bool live_exact = true; // `live` is the device's count (it is refreshed only now and then)
             for (int32_t bounce = 0; bounce < cam->max_depth && live > 0; ++bounce) {
                 if (live_exact && bounce > 0 && live <= tail_paths) {
@@ -885,7 +975,7 @@ int render_impl(rt_scene* s, const rt_camera* cam, uint64_t seed, const rt_work*
                     int fblocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)s->fast_grid_blocks, (waves + (FAST_BLOCK / 64) - 1) / (FAST_BLOCK / 64)));
                     hipLaunchKernelGGL(fast_kernel_paths(s->fast_prim, s->fast_quant), dim3(fblocks), dim3(FAST_BLOCK), 0, st, s->dev, s->flat.fast_root,
                                        view, (unsigned long long)live, rq, 1u, 0.001, s->fast_extent, out_t, out_prim, s->d_counters + C_WORK_SLOTS,
-                                       s->d_counters + C_NODES, s->fast_spill, k_refill, k_vote, k_chunk, k_pop);
+                                       s->d_counters + C_NODES, s->fast_spill, k_refill, k_vote, k_chunk, k_pop, (const PRay*)nullptr);
                 }
                 if (!fast_extend || s->flat.fast_partial) { // the whole world, or what follows its first member
                     if (fast_extend) hipLaunchKernelGGL(reset_work_kernel, dim3(1), dim3(1), 0, st, s->d_counters);
@@ -934,6 +1024,7 @@ int rt_scene_create(const rt_scene_desc* desc, uint32_t flags, rt_scene** out) {
     if (!out) return set_err(RT_E_INVALID, "rt_scene_create: null out pointer");
     *out = nullptr;
     rt_scene* s = new rt_scene();
+    s->tune = read_tuning();
     std::string err;
     int rc = flatten_scene(desc, s->flat, err);
     if (rc) { delete s; return set_err(rc, err); }
@@ -957,6 +1048,11 @@ int rt_scene_destroy(rt_scene* s) {
         free_workspace(s);
         for (void* p : s->allocs) (void)hipFree(p);
         if (s->hit_ctx) (void)hipFree(s->hit_ctx);
+        if (s->prep) (void)hipFree(s->prep);
+        if (s->prep_bins) (void)hipFree(s->prep_bins);
+        if (s->prep_hist) (void)hipFree(s->prep_hist);
+        if (s->ev_k0) (void)hipEventDestroy(s->ev_k0);
+        if (s->ev_k1) (void)hipEventDestroy(s->ev_k1);
         if (s->h_counters) (void)hipHostFree(s->h_counters);
         if (s->ev_hit0) (void)hipEventDestroy(s->ev_hit0);
         if (s->ev_hit1) (void)hipEventDestroy(s->ev_hit1);
@@ -1190,10 +1286,15 @@ int rt_get_counters(rt_scene* s, rt_counters* out) {
         HIP_TRY(hipMemcpy(s->h_counters, s->d_counters, C_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         s->counters.node_visits = s->h_counters[C_NODES];
         s->counters.prim_tests = s->h_counters[C_PRIMS];
-        if (s->hit_timed) { float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, s->ev_hit0, s->ev_hit1)); s->counters.ms_last_closest_hit = ms; }
+        if (s->hit_timed) {
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, s->ev_hit0, s->ev_hit1)); s->counters.ms_last_closest_hit = ms;
+            HIP_TRY(hipEventElapsedTime(&ms, s->ev_k0, s->ev_k1)); s->counters.ms_last_traversal = ms;
+            HIP_TRY(hipEventElapsedTime(&ms, s->ev_hit0, s->ev_k0)); s->counters.ms_last_reorder = s->hit_reordered ? ms : 0.0;
+        }
         if (s->render_timed) { float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, s->ev_r0, s->ev_r1)); s->counters.ms_last_render = ms; }
         s->counters.render_rays = s->h_counters[C_RAYS];
-        if (getenv("MI355RT_DEBUG")) {
+        if (s->tune.debug) {
 #ifdef RT_PHASE_STATS
             std::fprintf(stderr, "[mi355rt] shade wave cycles: record load %llu hit record %llu material %llu write-back %llu queue %llu\n", s->h_counters[24],
                          s->h_counters[25], s->h_counters[26], s->h_counters[27], s->h_counters[28]);
