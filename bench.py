@@ -1,20 +1,25 @@
 #!/usr/bin/env python3
 """bench.py -- closest-hit throughput of the HIP path on the 1M-triangle workload.
 
-One step = one rt_closest_hit_device launch over one batch of 2^24 incoherent f64 rays
+One step = one rt_closest_hit_device call over one batch of 2^24 incoherent f64 rays
 (origins uniform in the scene box, directions uniform on the sphere) against the
-2^20-triangle soup held as a Mesh (BVH in the reference's split order).  Rays and hit
-records are resident in HBM before the timed region.  Prints ONE JSON line (rank 0).
+2^20-triangle soup held as a Mesh (BVH in the reference's split order): the library's
+binning pass, the traversal kernel and the pass that completes the hit records.  Rays and
+hit records are resident in HBM before the timed region.  Prints ONE JSON line (rank 0).
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 With N > 1 every rank traces its own batch (weak scaling, no data-path collective); the
-time is the max over ranks between two barriers.
+time is the max over ranks between two barriers.  After that leg an N-rank job renders a
+bounded sample of the 4096 x 2304 mesh + spheres frame: every rank its band of the strata
+on its own GPU, then ONE sum-reduction of the f64 accumulator to rank 0 over RCCL
+(ray_tracer_amd.parallel.render_frame_job); reported under "multi_gpu_render".
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -24,8 +29,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
-VALU_PEAK_TINSTR = 256 * 64 * 2.4e9 / 1e12  # lane-instructions per second, in units of 1e12
-NODE_BYTES, TRI_BYTES, RAY_BYTES, HIT_BYTES = 64, 72, 72, 48
+NODE_BYTES, TRI_BYTES, RAY_BYTES, HIT_BYTES = 64, 72, 72, 48  # record sizes of the algorithmic-bytes formula
+
+
+def source_hash() -> str:
+    """Hash of the kernel sources: a profile under profiles/ only describes the build it was taken from."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "ray_tracer_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".h", ".hip", ".cpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def main() -> None:
@@ -39,7 +54,9 @@ def main() -> None:
     ap.add_argument("--cpu-sample", type=int, default=1 << 23, help="rays of the batch timed on the host cores")
     ap.add_argument("--count-sample", type=int, default=1 << 16, help="rays used for the reference-order visit counts")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-render", action="store_true", help="skip the camera-samples/s figure (second half of the metric)")
+    ap.add_argument("--no-render", action="store_true", help="skip the camera-samples/s figures (second half of the metric)")
+    ap.add_argument("--no-mesh", action="store_true", help="skip the closed-mesh closest-hit figure")
+    ap.add_argument("--frame-strata", type=int, default=64, help="strata per rank of the multi-GPU frame sample (of 4096)")
     args = ap.parse_args()
 
     import numpy as np
@@ -47,73 +64,82 @@ def main() -> None:
 
     import ray_tracer_amd as rt
     from ray_tracer_amd import _ffi as F
-    from ray_tracer_amd import scenes
+    from ray_tracer_amd import parallel, scenes
 
     rank = int(os.environ.get("RANK", "0"))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product has no CPU path")
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank)  # before any scene is created: a scene lives on the device current at rt_scene_create
     dev = torch.device("cuda", local_rank)
     dist = None
     if world_size > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
-    # ------------------------------------------------------------------ scene + batch
-    t0 = time.time()
-    mesh = scenes.triangle_soup_scene(args.triangles, seed=2)
-    desc = rt.SceneDesc.from_world(mesh)
-    scene = rt.Scene(desc)
-    info = scene.info()
-    build_s = time.time() - t0
-    bounds = [info.world_bounds[k] for k in range(6)]
-    o, d, tm = scenes.incoherent_rays(args.rays, bounds, seed=3 + rank)
-    rays = {}
-    for k, name in enumerate(("ox", "oy", "oz")):
-        rays[name] = torch.from_numpy(np.ascontiguousarray(o[:, k])).to(dev)
-    for k, name in enumerate(("dx", "dy", "dz")):
-        rays[name] = torch.from_numpy(np.ascontiguousarray(d[:, k])).to(dev)
-    rays["time"] = torch.from_numpy(tm).to(dev)
-    n = args.rays
-    hits = {"t": torch.empty(n, dtype=torch.float64, device=dev), "prim": torch.empty(n, dtype=torch.int32, device=dev),
-            "u": torch.empty(n, dtype=torch.float64, device=dev), "v": torch.empty(n, dtype=torch.float64, device=dev),
-            "front_face": torch.empty(n, dtype=torch.uint8, device=dev), "mat": torch.empty(n, dtype=torch.int32, device=dev)}
-    flags = F.RT_HIT_ORDERED if args.mode == "ordered" else F.RT_HIT_REFERENCE_ORDER
-    stream = torch.cuda.current_stream().cuda_stream
-
-    def step():
-        scene.closest_hit_device(rays, hits, n, seed=0, flags=flags, stream=stream)
-
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    kernel_ms = []
-    t_start = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        # device time of this launch from HIP events recorded on the launch stream
-        kernel_ms.append(scene.counters().ms_last_closest_hit)
-    barrier()
-    elapsed = time.perf_counter() - t_start
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    # one extra launch outside the timed region with the visit counters on: what this traversal actually did
-    scene.reset_counters()
-    scene.closest_hit_device(rays, hits, n, seed=0, flags=flags | F.RT_HIT_COUNTERS, stream=stream)
-    torch.cuda.synchronize()
-    cnt = scene.counters()
-    actual_nodes, actual_prims = cnt.node_visits / n, cnt.prim_tests / n
-    total_rays = float(n) * args.steps * world_size
-    mrays = total_rays / elapsed / 1e6
+    stream = torch.cuda.current_stream().cuda_stream
+    flags = F.RT_HIT_ORDERED if args.mode == "ordered" else F.RT_HIT_REFERENCE_ORDER
+    n = args.rays
+
+    def device_rays(o, d, tm):
+        rays = {}
+        for k, name in enumerate(("ox", "oy", "oz")):
+            rays[name] = torch.from_numpy(np.ascontiguousarray(o[:, k])).to(dev)
+        for k, name in enumerate(("dx", "dy", "dz")):
+            rays[name] = torch.from_numpy(np.ascontiguousarray(d[:, k])).to(dev)
+        rays["time"] = torch.from_numpy(tm).to(dev)
+        return rays
+
+    hits = {"t": torch.empty(n, dtype=torch.float64, device=dev), "prim": torch.empty(n, dtype=torch.int32, device=dev),
+            "u": torch.empty(n, dtype=torch.float64, device=dev), "v": torch.empty(n, dtype=torch.float64, device=dev),
+            "front_face": torch.empty(n, dtype=torch.uint8, device=dev), "mat": torch.empty(n, dtype=torch.int32, device=dev)}
+
+    def timed_steps(scene, rays, steps, warmup):
+        """`steps` calls between two barriers; device times from the library's HIP events on the launch stream."""
+        for _ in range(warmup):
+            scene.closest_hit_device(rays, hits, n, seed=0, flags=flags, stream=stream)
+        barrier()
+        scene.reset_counters()
+        t_start = time.perf_counter()
+        for _ in range(steps):
+            scene.closest_hit_device(rays, hits, n, seed=0, flags=flags, stream=stream)
+        barrier()
+        elapsed = time.perf_counter() - t_start
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        c = scene.counters()  # harvests the events of the calls above (at most 32 are kept)
+        k = max(1, c.timed_calls)
+        return elapsed, {"traversal_ms": c.ms_sum_traversal / k, "reorder_ms": c.ms_sum_reorder / k, "call_ms": c.ms_sum_closest_hit / k,
+                         "timed_calls": int(c.timed_calls)}
+
+    def actual_counts(scene, rays):
+        """One launch outside the timed region with the visit counters on: what this traversal actually did."""
+        scene.reset_counters()
+        scene.closest_hit_device(rays, hits, n, seed=0, flags=flags | F.RT_HIT_COUNTERS, stream=stream)
+        torch.cuda.synchronize()
+        c = scene.counters()
+        return c.node_visits / n, c.prim_tests / n
+
+    # ------------------------------------------------------------------ headline: the 2^20-triangle soup
+    t0 = time.time()
+    desc = rt.SceneDesc.from_world(scenes.triangle_soup_scene(args.triangles, seed=2))
+    scene = rt.Scene(desc)
+    info = scene.info()
+    build_s = time.time() - t0
+    bounds = [info.world_bounds[k] for k in range(6)]
+    o, d, tm = scenes.incoherent_rays(n, bounds, seed=3 + rank)
+    rays = device_rays(o, d, tm)
+    elapsed, dev_ms = timed_steps(scene, rays, args.steps, args.warmup)
+    box_tests, prim_tests = actual_counts(scene, rays)
+    mrays = float(n) * args.steps * world_size / elapsed / 1e6
     hit_frac = float((hits["prim"] != -1).double().mean().item())
 
     out = {
@@ -123,41 +149,13 @@ def main() -> None:
         "config": {"workload": f"closest-hit, {args.triangles}-triangle soup Mesh (BVH, reference split order), "
                                f"{n} incoherent f64 rays per GPU per step", "traversal": args.mode,
                    "bvh_nodes": int(info.n_nodes), "scene_bytes": int(info.device_bytes), "hit_fraction": hit_frac,
-                   "scene_build_s": build_s},
+                   "scene_build_s": build_s, "device_ms_per_step": dev_ms},
     }
 
     if rank == 0:
         import oracle_ffi as O  # the CPU oracle: checker and reported baseline only
         cpu = O.OracleScene(desc)
-        # reference-order visit counts per ray (define the algorithmic bytes of a launch)
-        m = min(args.count_sample, n)
-        ctr = {}
-        cpu.closest_hit(o[:m], d[:m], time=tm[:m], nthreads=min(16, os.cpu_count() or 1), counters=ctr)
-        nodes_per_ray = ctr["node_visits"] / m
-        prims_per_ray = ctr["prim_tests"] / m
-        bytes_per_ray = NODE_BYTES * nodes_per_ray + TRI_BYTES * prims_per_ray + RAY_BYTES + HIT_BYTES
-        avg_ms = float(np.mean(kernel_ms))
-        achieved = bytes_per_ray * n / (avg_ms * 1e-3) / 1e9
-        out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": _traffic_from_env(),
-                           "kernel": "bvh4_closest_hit_kernel" if args.mode == "ordered" else "closest_hit_kernel", "kernel_ms": avg_ms,
-                           "ref_order_nodes_per_ray": nodes_per_ray, "ref_order_prims_per_ray": prims_per_ray,
-                           "alg_bytes_per_ray": bytes_per_ray, "count_sample_rays": m,
-                           "actual_box_tests_per_ray": actual_nodes, "actual_prim_tests_per_ray": actual_prims,
-                           # ordered: 64-byte 4-wide nodes (16 B per child box tested), one 128-byte line per triangle
-                           "actual_bytes_per_ray": (16 * actual_nodes + 128 * actual_prims if args.mode == "ordered"
-                                                    else 64 * actual_nodes + 128 * actual_prims) + RAY_BYTES + HIT_BYTES}
-        out["roofline"]["achieved_actual"] = out["roofline"]["actual_bytes_per_ray"] * n / (avg_ms * 1e-3) / 1e9
-        # the second candidate roof: vector ALU lane-instructions (256 CUs x 64 lanes x 2.4 GHz), with the same
-        # reference-order visit counts: 45 per node visit (f64 slab test), 70 per triangle test, 40 per ray
-        instr_per_ray = 45.0 * nodes_per_ray + 70.0 * prims_per_ray + 40.0
-        valu_achieved = instr_per_ray * n / (avg_ms * 1e-3) / 1e12
-        out["roofline"]["valu"] = {"alg_lane_instr_per_ray": instr_per_ray, "achieved": valu_achieved, "peak": VALU_PEAK_TINSTR,
-                                   "unit": "T lane-instr/s", "frac": valu_achieved / VALU_PEAK_TINSTR}
-        if out["roofline"]["traffic"]:
-            # measured L2 <-> fabric bytes per launch (profiles/) over this run's kernel time: the binding roof
-            out["roofline"]["traffic_gbs"] = out["roofline"]["traffic"] / (avg_ms * 1e-3) / 1e9
-            out["roofline"]["traffic_frac"] = out["roofline"]["traffic_gbs"] / HBM_PEAK_GBS
+        out["roofline"] = _roofline(args, n, dev_ms, box_tests, prim_tests, cpu, o, d, tm, np)
         if not args.no_cpu and world_size == 1:
             threads = min(16, os.cpu_count() or 1)
             mc = min(args.cpu_sample, n)
@@ -167,24 +165,113 @@ def main() -> None:
             out["cpu_baseline"] = {"value": mc / cpu_s / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
                                    "sample": f"first {mc} rays of the same batch, C++ f64 restatement of the reference "
                                              f"(reference-order traversal), {threads} threads, {cpu_s:.1f} s"}
-            # the same restatement on one core, on a smaller slice of the batch
-            m1 = min(mc, max(1, mc // 16))
+            m1 = min(mc, max(1, mc // 16))  # the same restatement on one core, on a smaller slice of the batch
             t1 = time.perf_counter()
             cpu.closest_hit(o[:m1], d[:m1], time=tm[:m1], nthreads=1)
             one_s = time.perf_counter() - t1
             out["cpu_baseline"]["single_thread"] = {"value": m1 / one_s / 1e6, "unit": "Mrays/s", "sample": f"first {m1} rays, {one_s:.1f} s"}
-            got = hits["prim"][:mc].cpu().numpy().astype(np.uint32)
-            same = got == ref["prim"]
-            t_gpu = hits["t"][:mc].cpu().numpy()
-            tie = np.isclose(t_gpu, ref["t"], rtol=1e-6, atol=0) | (np.isinf(t_gpu) & np.isinf(ref["t"]))
-            out["config"]["parity_vs_oracle"] = {"rays": int(mc), "prim_mismatch_not_tie": int((~same & ~tie).sum()),
-                                                 "prim_mismatch_tie": int((~same & tie).sum())}
+            out["config"]["parity_vs_oracle"] = _parity(hits, ref, mc, np)
+        del cpu
+    scene.close()
+
+    # ------------------------------------------------------------------ the same batch size on a closed mesh of >= 1M triangles
+    if rank == 0 and world_size == 1 and not args.no_mesh:
+        out["mesh"] = _mesh_figure(rt, F, scenes, np, n, device_rays, timed_steps, actual_counts, hits, args)
+
     if rank == 0 and world_size == 1 and not args.no_render:
         out["render"] = {name: _render_figure(rt, F, scenes, np, name, with_cpu=not args.no_cpu) for name in ("book2_final", "cornell_box")}
+
+    # ------------------------------------------------------------------ the frame partitioned over the ranks + one reduce
+    if world_size > 1 and not args.no_render:
+        fig = _multi_gpu_render(rt, F, scenes, parallel, torch, dist, dev, stream, args.frame_strata * world_size)
+        if rank == 0:
+            out["multi_gpu_render"] = fig
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def _roofline(args, n, dev_ms, box_tests, prim_tests, cpu, o, d, tm, np):
+    """HBM roofline of the dominant kernel.  Algorithmic bytes per ray = 64 per node visit + 72 per triangle test +
+    72 (ray in) + 48 (hit out), with the visits THIS kernel made (a visit of a 4-wide node = 4 box tests), times the
+    rays of a launch, over the kernel's average duration in the timed region (HIP events of the library on the
+    launch stream).  The same formula on the reference-order counts of the oracle is reported beside it, with the
+    ratio of the two visit counts: it says how much work the ordered traversal avoids, not how fast the kernel is."""
+    kernel_ms = dev_ms["traversal_ms"]
+    ordered = args.mode == "ordered"
+    node_visits = box_tests / 4.0 if ordered else box_tests
+    own_bytes = NODE_BYTES * node_visits + TRI_BYTES * prim_tests + RAY_BYTES + HIT_BYTES
+    achieved = own_bytes * n / (kernel_ms * 1e-3) / 1e9
+    m = min(args.count_sample, n)
+    ctr = {}
+    cpu.closest_hit(o[:m], d[:m], time=tm[:m], nthreads=min(16, os.cpu_count() or 1), counters=ctr)
+    ref_nodes, ref_prims = ctr["node_visits"] / m, ctr["prim_tests"] / m
+    ref_bytes = NODE_BYTES * ref_nodes + TRI_BYTES * ref_prims + RAY_BYTES + HIT_BYTES
+    r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+         "kernel": "bvh4_closest_hit_kernel" if ordered else "closest_hit_kernel", "kernel_ms": kernel_ms,
+         "node_visits_per_ray": node_visits, "prim_tests_per_ray": prim_tests, "alg_bytes_per_ray": own_bytes,
+         "ref_order_nodes_per_ray": ref_nodes, "ref_order_prims_per_ray": ref_prims, "ref_order_bytes_per_ray": ref_bytes,
+         "ref_order_equivalent_gbs": ref_bytes * n / (kernel_ms * 1e-3) / 1e9, "visit_reduction": ref_bytes / own_bytes,
+         "count_sample_rays": m}
+    prof = _profile_for_this_build()
+    if prof:
+        # fabric-side bytes per launch from the rocprofv3 --pmc passes of the same command (profiles/), valid for this
+        # build only (source hash): L2 <-> Infinity Cache / HBM reads (FETCH_SIZE x 2 on gfx950) + writes
+        r["traffic"] = prof.get("hbm_bytes_per_launch")
+        if r["traffic"]:
+            r["traffic_gbs"] = r["traffic"] / (kernel_ms * 1e-3) / 1e9
+            r["traffic_frac"] = r["traffic_gbs"] / HBM_PEAK_GBS
+        for k in ("l2_hit_rate", "valu_busy_frac", "valu_lane_utilisation", "wave_wait_frac", "profile"):
+            if k in prof:
+                r[k] = prof[k]
+    return r
+
+
+def _profile_for_this_build():
+    p = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        prof = json.load(open(p))
+    except Exception:
+        return None
+    return prof if prof.get("source_hash") == source_hash() else None
+
+
+def _parity(hits, ref, mc, np):
+    got = hits["prim"][:mc].cpu().numpy().astype(np.uint32)
+    same = got == ref["prim"]
+    t_gpu = hits["t"][:mc].cpu().numpy()
+    tie = np.isclose(t_gpu, ref["t"], rtol=1e-6, atol=0) | (np.isinf(t_gpu) & np.isinf(ref["t"]))
+    return {"rays": int(mc), "prim_mismatch_not_tie": int((~same & ~tie).sum()), "prim_mismatch_tie": int((~same & tie).sum()),
+            "t_bit_identical": bool(np.array_equal(t_gpu, ref["t"]))}
+
+
+def _mesh_figure(rt, F, scenes, np, n, device_rays, timed_steps, actual_counts, hits, args):
+    """Closest hit on a closed 'bunny-class' surface of 1,310,720 triangles (icosphere, 8 subdivisions, smooth radial
+    displacement; no OBJ asset ships with the reference), same batch shape as the headline."""
+    import oracle_ffi as O
+    tris = scenes.icosphere_mesh(subdiv=8)
+    t0 = time.time()
+    desc = rt.SceneDesc.from_world(rt.Mesh(tris, rt.Lambertian(rt.Color(.5, .5, .5))))
+    scene = rt.Scene(desc)
+    build_s = time.time() - t0
+    b = scene.info().world_bounds
+    o, d, tm = scenes.incoherent_rays(n, [b[k] for k in range(6)], seed=5)
+    rays = device_rays(o, d, tm)
+    elapsed, dev_ms = timed_steps(scene, rays, args.steps, args.warmup)
+    box_tests, prim_tests = actual_counts(scene, rays)
+    fig = {"metric": "Mrays/s closest-hit", "scene": f"closed mesh, {len(tris)} triangles (icosphere subdiv 8, displaced), {n} incoherent f64 rays",
+           "value": float(n) * args.steps / elapsed / 1e6, "unit": "Mrays/s", "ms_per_step": 1e3 * elapsed / args.steps,
+           "device_ms_per_step": dev_ms, "scene_build_s": build_s, "hit_fraction": float((hits["prim"] != -1).double().mean().item()),
+           "node_visits_per_ray": box_tests / 4.0, "prim_tests_per_ray": prim_tests}
+    own_bytes = NODE_BYTES * box_tests / 4.0 + TRI_BYTES * prim_tests + RAY_BYTES + HIT_BYTES
+    fig["roofline_frac"] = own_bytes * n / (dev_ms["traversal_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+    if not args.no_cpu:
+        m = min(1 << 16, n)
+        ref = O.OracleScene(desc).closest_hit(o[:m], d[:m], time=tm[:m], nthreads=min(16, os.cpu_count() or 1))
+        fig["parity_vs_oracle"] = _parity(hits, ref, m, np)
+    scene.close()
+    return fig
 
 
 def _render_figure(rt, F, scenes, np, name, with_cpu):
@@ -205,8 +292,10 @@ def _render_figure(rt, F, scenes, np, name, with_cpu):
     t0 = time.perf_counter()
     accum = gpu.render(c, seed=1)
     wall = time.perf_counter() - t0
+    cnt = gpu.counters()
     fig = {"metric": "camera samples/s", "scene": f"{name} {cam.image_width}x{d.image_height}, {n_strata} samples/pixel, depth {cam.max_depth}",
-           "value": paths / wall, "unit": "samples/s", "ms_frame": 1e3 * wall, "device_ms": gpu.counters().ms_last_render}
+           "value": paths / wall, "unit": "samples/s", "ms_frame": 1e3 * wall, "device_ms": cnt.ms_last_render,
+           "extend_queries": int(cnt.render_rays)}
     if with_cpu:
         import oracle_ffi as O
         rows, threads = (200 if name == "book2_final" else 600), min(16, os.cpu_count() or 1)
@@ -220,18 +309,46 @@ def _render_figure(rt, F, scenes, np, name, with_cpu):
         fig["cpu_baseline"] = {"value": cam.image_width * rows * n_strata / cpu_s, "unit": "samples/s", "cores": threads, "kind": "port",
                                "sample": f"{rows} image rows of the same frame, all strata, {cpu_s:.1f} s"}
         fig["rmse_vs_oracle_rows"] = float(np.sqrt(np.mean((sa - sb) ** 2)))
+    gpu.close()
     return fig
 
 
-def _traffic_from_env():
-    """HBM bytes per launch from a separate rocprofv3 --pmc pass, when one was recorded (profiles/)."""
-    p = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(p):
-        try:
-            return json.load(open(p)).get("hbm_bytes_per_launch")
-        except Exception:
-            return None
-    return None
+def _multi_gpu_render(rt, F, scenes, parallel, torch, dist, dev, stream, strata_total):
+    """The 4096 x 2304 mesh + spheres frame (4096 strata) as an N-rank job: every rank builds the scene on ITS device,
+    renders its band of the first `strata_total` strata with rt_render_device, then one reduce (sum) of the f64
+    accumulator to rank 0 over RCCL.  The frame does not depend on the partition (streams are keyed by pixel and
+    stratum); rank 0 checks the reduced sum against its own contribution plus the others' pixel sums."""
+    world, lights, cam = scenes.mesh_and_spheres(image_width=4096, samples_per_pixel=4096, max_depth=50)
+    scene = rt.Scene(rt.SceneDesc.from_world(world, lights))  # created with this rank's device current
+    c, d = cam.to_struct(), cam.derived()
+    n_strata = d.sqrt_spp * d.sqrt_spp
+    accum = torch.zeros((d.image_height, cam.image_width, 3), dtype=torch.float64, device=dev)
+
+    def render_unit(work, acc):
+        scene.render_device(c, acc, seed=7, work=work, stream=stream)
+
+    # warm-up on one stratum (path workspace, code objects, RCCL channel set-up), then the timed job
+    warm = torch.zeros_like(accum)
+    parallel.render_frame_job(render_unit, warm, cam.image_width, d.image_height, n_strata, dist=dist, strata_limit=dist.get_world_size(),
+                              sync=torch.cuda.synchronize)
+    dist.barrier()
+    accum, tm = parallel.render_frame_job(render_unit, accum, cam.image_width, d.image_height, n_strata, dist=dist,
+                                          strata_limit=strata_total, sync=torch.cuda.synchronize)
+    gathered = [None] * dist.get_world_size()
+    dist.all_gather_object(gathered, tm)
+    total_s = max(g["render_s"] + g["reduce_s"] for g in gathered)
+    paths = sum(g["paths"] for g in gathered)
+    fig = {"metric": "camera samples/s", "scene": f"mesh + spheres {cam.image_width}x{d.image_height}, strata [0, {strata_total}) of {n_strata}, depth {cam.max_depth}",
+           "partition": "strata", "collective": "reduce(sum) of the f64 accumulator to rank 0 (nccl = RCCL)",
+           "nccl_world_size": dist.get_world_size(), "backend": dist.get_backend(), "value": paths / total_s, "unit": "samples/s",
+           "paths": paths, "per_rank_render_ms": [1e3 * g["render_s"] for g in gathered], "per_rank_reduce_ms": [1e3 * g["reduce_s"] for g in gathered],
+           "accumulator_bytes": accum.numel() * 8}
+    if dist.get_rank() == 0:
+        a = accum.sum().item()
+        fig["accumulator_sum_finite"] = bool(a == a)
+        fig["mean_radiance"] = float(torch.nan_to_num(accum).mean().item() / max(1, strata_total))
+    scene.close()
+    return fig
 
 
 if __name__ == "__main__":

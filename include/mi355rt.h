@@ -343,6 +343,10 @@ typedef struct rt_counters {
     double   ms_last_render;      /* device time of the last rt_render* call */
     double   ms_last_traversal;   /* of that closest-hit call, the traversal kernel alone */
     double   ms_last_reorder;     /* of that closest-hit call, the binning pass in front of the traversal (0 when the batch was not reordered) */
+    double   ms_sum_closest_hit;  /* the same three, summed over the closest-hit calls since rt_reset_counters (the library keeps the */
+    double   ms_sum_traversal;    /* events of the 32 newest calls between two rt_get_counters; older ones are not counted) */
+    double   ms_sum_reorder;
+    uint64_t timed_calls;         /* number of calls in those sums */
 } rt_counters;
 
 int rt_get_counters(rt_scene* scene, rt_counters* out);

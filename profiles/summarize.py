@@ -50,10 +50,18 @@ if mean:
     fetch = mean.get("FETCH_SIZE", 0) * 1024 * 2  # gfx950: FETCH_SIZE tallies 128-B requests at 64 B (calibrated on a
     write = mean.get("WRITE_SIZE", 0) * 1024      # random 128-B row gather, profiles/fetch_calib.hip: factor 2.000)
     traffic = fetch + write
-    json.dump({"hbm_bytes_per_launch": traffic, "fetch_bytes": fetch, "write_bytes": write,
-               "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, {tag}; FETCH_SIZE doubled per the gfx950 "
-                         "calibration (profiles/fetch_calib.hip measured 1.9996)"}, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
     ms = (avg_ns or 0) / 1e6
+    sys.path.insert(0, root)
+    from bench import source_hash  # the profile describes this build only: bench.py ignores it once the kernel sources change
+    simd_cycles = 256 * 4 * cyc    # SQ_ACTIVE_INST_VALU counts quad-cycles (4 shader cycles), summed over the SIMDs
+    json.dump({"source_hash": source_hash(), "profile": f"profiles/{tag}_counters.csv",
+               "hbm_bytes_per_launch": traffic, "fetch_bytes": fetch, "write_bytes": write,
+               "l2_hit_rate": mean.get("TCC_HIT_sum", 0) / max(1.0, mean.get("TCC_HIT_sum", 0) + mean.get("TCC_MISS_sum", 0)),
+               "valu_busy_frac": 4.0 * mean.get("SQ_ACTIVE_INST_VALU", 0) / max(1.0, simd_cycles),
+               "valu_lane_utilisation": mean.get("SQ_THREAD_CYCLES_VALU", 0) / max(1.0, 64 * mean.get("SQ_ACTIVE_INST_VALU", 0)),
+               "wave_wait_frac": mean.get("SQ_WAIT_ANY", 0) / max(1.0, mean.get("SQ_WAVE_CYCLES", 0)),
+               "source": f"rocprofv3 --pmc, separate passes, {tag}; FETCH_SIZE doubled per the gfx950 "
+                         "calibration (profiles/fetch_calib.hip measured 1.9996)"}, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
     lines += [
         f"* shader clock during the kernel: {cyc / (ms * 1e-3) / 1e9:.2f} GHz (GRBM_GUI_ACTIVE / 8 / duration)" if ms else "",
         f"* fabric-side traffic (L2 <-> Infinity Cache / HBM): {traffic / 1e9:.1f} GB per launch = "
@@ -62,6 +70,7 @@ if mean:
         f"({mean.get('TCC_REQ_sum', 0):.3g} requests)",
         f"* texture addresser busy: {100 * mean.get('TA_TA_BUSY_sum', 0) / max(1.0, 256 * cyc):.0f} % of 256 CUs x kernel cycles; "
         f"L1 accesses {mean.get('TCP_TOTAL_CACHE_ACCESSES_sum', 0):.3g}",
+        f"* vector ALU busy (4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x kernel cycles)): {100 * 4.0 * mean.get('SQ_ACTIVE_INST_VALU', 0) / max(1.0, 256 * 4 * cyc):.0f} %",
         f"* waves {mean.get('SQ_WAVES', 0):.0f}; wave time waiting (SQ_WAIT_ANY / SQ_WAVE_CYCLES): "
         f"{100 * mean.get('SQ_WAIT_ANY', 0) / max(1.0, mean.get('SQ_WAVE_CYCLES', 0)):.0f} %",
         f"* VALU lane utilisation (SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)): "
@@ -72,8 +81,9 @@ if mean:
 if bench:
     r = bench.get("roofline", {})
     lines += ["", f"bench.py line of the same build: {bench.get('value', 0):.1f} Mrays/s, {bench.get('ms_per_step', 0):.2f} ms/step, "
-                  f"roofline.achieved {r.get('achieved', 0):.0f} GB/s (reference-order algorithmic bytes), "
-                  f"actual {r.get('achieved_actual', 0):.0f} GB/s of node/triangle gathers, cpu_baseline "
+                  f"device ms per step {bench.get('config', {}).get('device_ms_per_step')}, "
+                  f"roofline.achieved {r.get('achieved', 0):.0f} GB/s = {r.get('frac', 0):.3f} of peak (bytes of the kernel's own visits), "
+                  f"reference-order equivalent {r.get('ref_order_equivalent_gbs', 0):.0f} GB/s (visit reduction {r.get('visit_reduction', 0):.2f}x), cpu_baseline "
                   f"{bench.get('cpu_baseline', {}).get('value', 0):.3f} Mrays/s on {bench.get('cpu_baseline', {}).get('cores', 0)} threads."]
 open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(l for l in lines if l is not None) + "\n")
 print(open(os.path.join(dst, f"{tag}_summary.md")).read())

@@ -134,7 +134,9 @@ class rt_work(C.Structure):
 class rt_counters(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("node_visits", C.c_uint64), ("prim_tests", C.c_uint64), ("paths", C.c_uint64),
                 ("render_rays", C.c_uint64), ("extend_launches", C.c_uint64), ("ms_last_closest_hit", C.c_double),
-                ("ms_last_render", C.c_double), ("ms_last_traversal", C.c_double), ("ms_last_reorder", C.c_double)]
+                ("ms_last_render", C.c_double), ("ms_last_traversal", C.c_double), ("ms_last_reorder", C.c_double),
+                ("ms_sum_closest_hit", C.c_double), ("ms_sum_traversal", C.c_double), ("ms_sum_reorder", C.c_double),
+                ("timed_calls", C.c_uint64)]
 
 
 # Every symbol include/mi355rt.h declares, with its prototype.

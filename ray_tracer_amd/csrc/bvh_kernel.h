@@ -86,6 +86,10 @@ struct LaneStack {
 // here: it issues the loads of all 64 lanes whether or not they stand on a node, and its 8 KB of
 // staging per wave costs occupancy.
 
+// Ballot of a boolean: the lane mask the compiler already keeps for it.  (HIP's __ballot takes an int, which costs a
+// select and a compare per call to turn the mask into a register and back; the loop below votes five times per step.)
+#define RT_BALLOT(pred) ((unsigned long long)__builtin_amdgcn_ballot_w64(pred))
+
 RT_DEV float ubyte_f32(uint32_t w, int byte) { return (float)((w >> (8 * byte)) & 0xFFu); } // v_cvt_f32_ubyteN
 
 // PRIM: RT_REF_TRI / RT_REF_SPHERE / RT_REF_QUAD when every leaf has that kind, 0 for mixed leaves.
@@ -153,7 +157,7 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, 
     for (;;) {
         if (COUNT) ++d_rounds;
         if (more) {
-            const unsigned long long idle = __ballot(!active);
+            const unsigned long long idle = RT_BALLOT(!active);
             if (idle) {
                 // The wave owns a private range [wave_next, wave_end) of the batch and takes a new one of
                 // `chunk` rays only when it is used up: one atomic per chunk instead of one per refill
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, 
             }
         }
         RT_TICK(c_refill);
-        if (!__any(active)) break;
+        if (!RT_BALLOT(active)) break;
 
         // Wave-uniform loop: runs until the wave is empty or enough lanes are idle to refill.
         for (;;) {
@@ -223,7 +227,7 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, 
             // Holding primitive tests back until a quorum is reached keeps the f64 intersector from
             // running with a handful of lanes while the rest of the wave waits.
             const bool at_node = active && !pop && (cur >> 28) == REF_QNODE;
-            if (COUNT) { ++d_iters; d_run_lanes += __popcll(__ballot(active)); d_node_lanes += __popcll(__ballot(at_node)); }
+            if (COUNT) { ++d_iters; d_run_lanes += __popcll(RT_BALLOT(active)); d_node_lanes += __popcll(RT_BALLOT(at_node)); }
             if (at_node) {
                 uint4 ch;
                 float nx[4], fx[4], ny[4], fy[4], nz[4], fz[4]; // entry / exit plane per axis and child
@@ -301,8 +305,8 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, 
             RT_TICK(c_node);
             {
                 const bool at_leaf = active && !pop && (cur >> 28) != REF_QNODE;
-                const unsigned long long leaf_mask = __ballot(at_leaf);
-                const unsigned long long run_mask = __ballot(active);
+                const unsigned long long leaf_mask = RT_BALLOT(at_leaf);
+                const unsigned long long run_mask = RT_BALLOT(active);
                 const bool quorum = __popcll(leaf_mask) >= leaf_vote || leaf_mask == run_mask;
                 if (COUNT && quorum && leaf_mask) { ++d_tri_phases; d_tri_lanes += __popcll(leaf_mask); }
                 if (at_leaf && quorum) {
@@ -327,7 +331,7 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, 
                 }
             }
             RT_TICK(c_leaf);
-            if (COUNT) { const unsigned long long pm = __ballot(pop); if (pm) { ++d_pop_iters; d_pop_lanes += __popcll(pm); } }
+            if (COUNT) { const unsigned long long pm = RT_BALLOT(pop); if (pm) { ++d_pop_iters; d_pop_lanes += __popcll(pm); } }
             if (pop) {
                 // At most pop_trips entries are taken per iteration.  After a hit most of a lane's stack is
                 // stale (farther than the hit); discarding it all at once would keep the whole wave in this
@@ -349,7 +353,7 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, 
                 }
             }
             RT_TICK(c_pop);
-            const int running = __popcll(__ballot(active));
+            const int running = __popcll(RT_BALLOT(active));
             if (running == 0 || (more && running < refill_threshold)) break;
         }
     }

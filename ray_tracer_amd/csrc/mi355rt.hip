@@ -526,10 +526,13 @@ struct Tuning {
     bool shade_textures = false; // MI355RT_SHADE_TEXTURES=1: always the full shading kernel
     bool reorder = true;         // MI355RT_REORDER=0: no binning pass in front of large closest-hit batches
     bool debug = false;          // MI355RT_DEBUG: diagnostics on stderr
+    int fast_blocks_per_cu = 0;  // MI355RT_FAST_BLOCKS_PER_CU: cap on the primitive-BVH kernel's workgroups per CU (occupancy experiments)
     uint64_t reorder_min = 1ull << 18; // smallest batch that is binned
     uint64_t tail_paths = 1ull << 16;
     uint64_t max_paths = 1ull << 27;
 };
+
+constexpr int HIT_RING = 32;
 
 struct rt_scene {
     FlatScene flat;
@@ -540,8 +543,13 @@ struct rt_scene {
     uint64_t device_bytes = 0;
     unsigned long long* d_counters = nullptr;
     unsigned long long* h_counters = nullptr; // pinned
-    hipEvent_t ev_hit0 = nullptr, ev_hit1 = nullptr, ev_r0 = nullptr, ev_r1 = nullptr;
-    bool hit_timed = false, render_timed = false;
+    // HIP events of the closest-hit calls since the counters were last read: a ring of HIT_RING launches, each with
+    // {call start, traversal start, traversal end, call end}, harvested by rt_get_counters
+    hipEvent_t ev_hit[HIT_RING][4] = {};
+    bool hit_reordered_at[HIT_RING] = {};
+    uint64_t hit_launches = 0, hit_harvested = 0;
+    hipEvent_t ev_r0 = nullptr, ev_r1 = nullptr;
+    bool render_timed = false;
     rt_counters counters{};
     int grid_blocks = 0;
     int fast_grid_blocks = 0;
@@ -565,8 +573,6 @@ struct rt_scene {
     uint32_t* prep_cursor = nullptr; // REORDER_BINS words
     uint64_t prep_cap = 0;
     ReorderGrid grid{};
-    hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr; // around the traversal kernel of the last closest-hit call
-    bool hit_reordered = false;
     Tuning tune;
 };
 
@@ -647,6 +653,7 @@ Tuning read_tuning() {
     t.shade_textures = env_int("MI355RT_SHADE_TEXTURES", 0) != 0;
     t.reorder = env_int("MI355RT_REORDER", 1) != 0;
     t.debug = getenv("MI355RT_DEBUG") != nullptr;
+    t.fast_blocks_per_cu = env_int("MI355RT_FAST_BLOCKS_PER_CU", 0);
     t.reorder_min = (uint64_t)std::max(1, env_int("MI355RT_REORDER_MIN", (int)t.reorder_min));
     t.tail_paths = (uint64_t)std::max(0, env_int("MI355RT_TAIL_PATHS", TAIL_PATHS));
     // Paths per render batch.  17 GB of path records and queues when a frame is that large (the workspace is sized
@@ -687,6 +694,7 @@ int pick_grid(rt_scene* s) {
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fast_per_cu, fast_kernel(s->fast_prim, false, s->fast_quant), FAST_BLOCK, 0));
         if (s->tune.debug)
             fprintf(stderr, "[mi355rt] primitive-BVH kernel: 8-bit nodes=%d (inflation %.3f) blocks/CU=%d\n", (int)s->fast_quant, s->flat.quant_inflation, fast_per_cu);
+        if (s->tune.fast_blocks_per_cu > 0) fast_per_cu = std::min(fast_per_cu, s->tune.fast_blocks_per_cu);
         s->fast_grid_blocks = prop.multiProcessorCount * std::max(1, fast_per_cu);
         {
             size_t entries = (size_t)std::max<uint32_t>(s->flat.fast_stack, 1u);
@@ -744,12 +752,10 @@ int upload_scene(rt_scene* s) {
     s->d_counters = static_cast<unsigned long long*>(c);
     HIP_TRY(hipMemset(c, 0, C_ALLOC * sizeof(unsigned long long)));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_counters), C_WORDS * sizeof(unsigned long long)));
-    HIP_TRY(hipEventCreate(&s->ev_hit0));
-    HIP_TRY(hipEventCreate(&s->ev_hit1));
+    for (int k = 0; k < HIT_RING; ++k)
+        for (int e = 0; e < 4; ++e) HIP_TRY(hipEventCreate(&s->ev_hit[k][e]));
     HIP_TRY(hipEventCreate(&s->ev_r0));
     HIP_TRY(hipEventCreate(&s->ev_r1));
-    HIP_TRY(hipEventCreate(&s->ev_k0));
-    HIP_TRY(hipEventCreate(&s->ev_k1));
     {   // grid of the reorder pass: 16 cells per axis over the world's box (a degenerate or unbounded axis gets one cell)
         const double* wb = s->flat.world_bounds.b;
         for (int k = 0; k < 3; ++k) {
@@ -817,7 +823,8 @@ int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit
     HIP_TRY(hipMemsetAsync(s->d_counters + C_WORK_SLOTS, 0, WORK_SLOTS * WORK_STRIDE * sizeof(unsigned long long), st));
     uint64_t waves = (n + 63) / 64;
     int blocks = (int)std::min<uint64_t>((uint64_t)s->grid_blocks, (waves + (BLOCK / 64) - 1) / (BLOCK / 64));
-    HIP_TRY(hipEventRecord(s->ev_hit0, st));
+    hipEvent_t* const ev = s->ev_hit[s->hit_launches % HIT_RING]; // start, traversal start, traversal end, end
+    HIP_TRY(hipEventRecord(ev[0], st));
     const bool count = flags & RT_HIT_COUNTERS, ordered = flags & RT_HIT_ORDERED;
     const Tuning& tn = s->tune;
     if (ordered && s->flat.fast_root != RT_REF_NONE && !s->flat.fast_partial) {
@@ -838,19 +845,19 @@ int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit
                                (unsigned long long)n, opt, 0.001, s->fast_extent, (const uint16_t*)s->prep_bins, s->prep_cursor, s->prep);
             HIP_TRY(hipGetLastError());
         }
-        HIP_TRY(hipEventRecord(s->ev_k0, st));
+        HIP_TRY(hipEventRecord(ev[1], st));
         hipLaunchKernelGGL(reorder ? fast_kernel_prepared(s->fast_prim, count, s->fast_quant) : fast_kernel(s->fast_prim, count, s->fast_quant),
                            dim3(fblocks), dim3(FAST_BLOCK), 0, st, s->dev, s->flat.fast_root, *rays, (unsigned long long)n, rq, opt, 0.001,
                            s->fast_extent, hits->t, hits->prim, s->d_counters + C_WORK_SLOTS, s->d_counters + C_NODES, s->fast_spill,
                            reorder ? tn.prep_refill : tn.refill, reorder ? tn.prep_vote : tn.vote, tn.chunk, tn.pop_trips, (const PRay*)s->prep);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(s->ev_k1, st));
+        HIP_TRY(hipEventRecord(ev[2], st));
         if (hits->u || hits->v || hits->front_face || hits->mat || hits->nx || hits->ny || hits->nz || hits->px || hits->py || hits->pz)
             hipLaunchKernelGGL(finalize_hits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s->dev, *rays, (unsigned long long)n, *hits, (const int32_t*)nullptr);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(s->ev_hit1, st)); // the whole call: reorder pass, traversal, record completion
-        s->hit_timed = true;
-        s->hit_reordered = reorder;
+        HIP_TRY(hipEventRecord(ev[3], st)); // the whole call: reorder pass, traversal, record completion
+        s->hit_reordered_at[s->hit_launches % HIT_RING] = reorder;
+        ++s->hit_launches;
         s->counters.rays += n;
         return RT_OK;
     }
@@ -876,7 +883,7 @@ int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemsetAsync(s->d_counters + C_WORK_SLOTS, 0, WORK_SLOTS * WORK_STRIDE * sizeof(unsigned long long), st));
     }
-    HIP_TRY(hipEventRecord(s->ev_k0, st));
+    HIP_TRY(hipEventRecord(ev[1], st));
     auto launch = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3(blocks), dim3(BLOCK), 0, st, s->dev, *rays, (unsigned long long)n, *hits, hit_ctx, (unsigned long long)seed, s->d_counters,
                            split ? 1 : 0);
@@ -892,12 +899,12 @@ int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit
         else if (ordered) launch(closest_hit_kernel<false, true, false>);
         else launch(closest_hit_kernel<false, false, false>);
     }
-    HIP_TRY(hipEventRecord(s->ev_k1, st));
+    HIP_TRY(hipEventRecord(ev[2], st));
     hipLaunchKernelGGL(finalize_hits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s->dev, *rays, (unsigned long long)n, *hits, (const int32_t*)hit_ctx);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(s->ev_hit1, st));
-    s->hit_timed = true;
-    s->hit_reordered = false;
+    HIP_TRY(hipEventRecord(ev[3], st));
+    s->hit_reordered_at[s->hit_launches % HIT_RING] = false;
+    ++s->hit_launches;
     s->counters.rays += n;
     return RT_OK;
 }
@@ -1051,11 +1058,9 @@ int rt_scene_destroy(rt_scene* s) {
         if (s->prep) (void)hipFree(s->prep);
         if (s->prep_bins) (void)hipFree(s->prep_bins);
         if (s->prep_hist) (void)hipFree(s->prep_hist);
-        if (s->ev_k0) (void)hipEventDestroy(s->ev_k0);
-        if (s->ev_k1) (void)hipEventDestroy(s->ev_k1);
         if (s->h_counters) (void)hipHostFree(s->h_counters);
-        if (s->ev_hit0) (void)hipEventDestroy(s->ev_hit0);
-        if (s->ev_hit1) (void)hipEventDestroy(s->ev_hit1);
+        for (int k = 0; k < HIT_RING; ++k)
+            for (int e = 0; e < 4; ++e) if (s->ev_hit[k][e]) (void)hipEventDestroy(s->ev_hit[k][e]);
         if (s->ev_r0) (void)hipEventDestroy(s->ev_r0);
         if (s->ev_r1) (void)hipEventDestroy(s->ev_r1);
     }
@@ -1286,11 +1291,18 @@ int rt_get_counters(rt_scene* s, rt_counters* out) {
         HIP_TRY(hipMemcpy(s->h_counters, s->d_counters, C_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         s->counters.node_visits = s->h_counters[C_NODES];
         s->counters.prim_tests = s->h_counters[C_PRIMS];
-        if (s->hit_timed) {
-            float ms = 0;
-            HIP_TRY(hipEventElapsedTime(&ms, s->ev_hit0, s->ev_hit1)); s->counters.ms_last_closest_hit = ms;
-            HIP_TRY(hipEventElapsedTime(&ms, s->ev_k0, s->ev_k1)); s->counters.ms_last_traversal = ms;
-            HIP_TRY(hipEventElapsedTime(&ms, s->ev_hit0, s->ev_k0)); s->counters.ms_last_reorder = s->hit_reordered ? ms : 0.0;
+        // closest-hit calls since the last harvest (at most the HIT_RING newest still have their events)
+        if (s->hit_launches - s->hit_harvested > (uint64_t)HIT_RING) s->hit_harvested = s->hit_launches - HIT_RING;
+        for (; s->hit_harvested < s->hit_launches; ++s->hit_harvested) {
+            hipEvent_t* const ev = s->ev_hit[s->hit_harvested % HIT_RING];
+            float call = 0, trav = 0, pre = 0;
+            HIP_TRY(hipEventElapsedTime(&call, ev[0], ev[3]));
+            HIP_TRY(hipEventElapsedTime(&trav, ev[1], ev[2]));
+            HIP_TRY(hipEventElapsedTime(&pre, ev[0], ev[1]));
+            if (!s->hit_reordered_at[s->hit_harvested % HIT_RING]) pre = 0;
+            s->counters.ms_last_closest_hit = call; s->counters.ms_last_traversal = trav; s->counters.ms_last_reorder = pre;
+            s->counters.ms_sum_closest_hit += call; s->counters.ms_sum_traversal += trav; s->counters.ms_sum_reorder += pre;
+            s->counters.timed_calls += 1;
         }
         if (s->render_timed) { float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, s->ev_r0, s->ev_r1)); s->counters.ms_last_render = ms; }
         s->counters.render_rays = s->h_counters[C_RAYS];
@@ -1315,6 +1327,7 @@ int rt_get_counters(rt_scene* s, rt_counters* out) {
 int rt_reset_counters(rt_scene* s) {
     if (!s) return set_err(RT_E_INVALID, "rt_reset_counters: null scene");
     s->counters = rt_counters{};
+    s->hit_harvested = s->hit_launches;
     if (!s->host_only) {
         HIP_TRY(hipSetDevice(s->device));
         HIP_TRY(hipDeviceSynchronize());

@@ -58,6 +58,36 @@ def render_distributed(render_unit: Callable[[F.rt_work, "object"], None], accum
     return accum
 
 
+def render_frame_job(render_unit: Callable[[F.rt_work, "object"], None], accum, width: int, height: int, n_strata: int,
+                     dist=None, mode: str = "strata", strata_limit: Optional[int] = None, sync: Optional[Callable[[], None]] = None,
+                     dst: int = 0):
+    """One frame as a multi-rank job, timed: this rank's units of the partition, then the one sum-reduction of the
+    accumulator to rank `dst`.  `strata_limit` renders only strata [0, limit) of the camera's grid (a bounded
+    sample of a frame whose full sample count would take minutes); `sync` blocks until the rank's device is idle
+    (torch.cuda.synchronize for the GPU renderer, nothing for a CPU renderer).  Returns (accum, timings) where
+    timings = {"rank", "world_size", "strata", "paths", "render_s", "reduce_s"}; the same function serves the
+    benchmark (RCCL) and the CPU tests (gloo).
+    """
+    import time
+    rank = dist.get_rank() if dist is not None else 0
+    world = dist.get_world_size() if dist is not None else 1
+    used = n_strata if strata_limit is None else max(0, min(n_strata, int(strata_limit)))
+    sync = sync or (lambda: None)
+    sync()
+    t0 = time.perf_counter()
+    paths = 0
+    for work in partition_frame(width, height, used, rank, world, mode):
+        render_unit(work, accum)
+        paths += (work.x1 - work.x0) * (work.y1 - work.y0) * (work.sample_end - work.sample_begin)
+    sync()
+    t1 = time.perf_counter()
+    if dist is not None and world > 1:
+        dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM)
+        sync()
+    t2 = time.perf_counter()
+    return accum, {"rank": rank, "world_size": world, "strata": used, "paths": paths, "render_s": t1 - t0, "reduce_s": t2 - t1}
+
+
 def shard_rays(n: int, rank: int, world_size: int) -> tuple:
     """Contiguous ray range of `rank` for a closest-hit batch of n rays (no exchange; hits stay local
     or are gathered by the caller)."""

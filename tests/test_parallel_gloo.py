@@ -60,9 +60,18 @@ def _worker(rank, world, port, mode, out_path):
             cpu.render(c, seed=11, work=work, accum=acc.numpy(), nthreads=2)
 
         parallel.render_distributed(render_unit, accum, cam.image_width, d.image_height, d.sqrt_spp * d.sqrt_spp, mode=mode, dist=dist)
+        # the timed job of bench.py --gpus N (same partition, same reduce), on a bounded sample of the strata
+        acc2 = torch.zeros_like(accum)
+        acc2, tm = parallel.render_frame_job(render_unit, acc2, cam.image_width, d.image_height, d.sqrt_spp * d.sqrt_spp, dist=dist,
+                                             mode=mode, strata_limit=5)
+        assert tm["world_size"] == world and tm["rank"] == rank and tm["strata"] == 5 and tm["render_s"] >= 0 and tm["reduce_s"] >= 0
+        counts = [None] * world
+        dist.all_gather_object(counts, tm["paths"])
         if rank == 0:
+            assert sum(counts) == cam.image_width * d.image_height * 5  # every (pixel, stratum) of the sample exactly once
             full = cpu.render(c, seed=11, nthreads=2)
-            np.save(out_path, np.stack([accum.numpy(), full]))
+            part = cpu.render(c, seed=11, work=F.rt_work(0, 0, cam.image_width, d.image_height, 0, 5), nthreads=2)
+            np.save(out_path, np.stack([accum.numpy(), full, acc2.numpy(), part]))
     finally:
         dist.destroy_process_group()
 
@@ -72,6 +81,7 @@ def test_two_rank_render_equals_unsplit_frame(tmp_path, mode):
     import torch.multiprocessing as mp
     out = str(tmp_path / f"r_{mode}.npy")
     mp.spawn(_worker, args=(2, _free_port(), mode, out), nprocs=2, join=True)
-    got, full = np.load(out)
+    got, full, got5, part5 = np.load(out)
     assert full.mean() > 1e-3
     assert np.allclose(np.nan_to_num(got), np.nan_to_num(full), rtol=1e-12, atol=1e-14)
+    assert np.allclose(np.nan_to_num(got5), np.nan_to_num(part5), rtol=1e-12, atol=1e-14)
