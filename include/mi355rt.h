@@ -187,7 +187,7 @@ typedef struct rt_bvh_node { /* 64 bytes */
     double   bounds[6]; /* xmin xmax ymin ymax zmin zmax (aabb.rs:10-14) */
     uint32_t left;      /* reference: bvh.rs:8 */
     uint32_t right;     /* reference: bvh.rs:9; equals left for a one-object span (bvh.rs:41-44) */
-    uint32_t flags;     /* bit 0: subtree contains a constant medium */
+    uint32_t flags;     /* bit 0: subtree contains a constant medium; bits 1-2: longest axis of the box (bvh.rs:32), along which the objects were split */
     uint32_t _pad;
 } rt_bvh_node;
 
@@ -248,8 +248,16 @@ typedef struct rt_hit_batch {
 
 /* rt_closest_hit flags */
 #define RT_HIT_REFERENCE_ORDER 0u /* left-then-right, list order: visit order of bvh.rs:118-140 */
-#define RT_HIT_ORDERED         1u /* near-child-first traversal; same closest hit, ties may resolve to another primitive at equal t */
+#define RT_HIT_ORDERED         1u /* near-child-first traversal over conservative boxes; same closest hit, ties may resolve to another
+                                     primitive at equal t.  One deviation beyond ties: a ray whose entry into a box coincides exactly
+                                     with its exit (through an edge or a corner) is culled there by the reference (aabb.rs:102) but not
+                                     by the conservative test, so a primitive touching that edge can be hit here and not there. */
 #define RT_HIT_COUNTERS        2u /* also accumulate node-visit / primitive-test counters (slower) */
+#define RT_HIT_EXACT_CULL      4u /* with RT_HIT_ORDERED: every box is tested exactly as Aabb::hit does (aabb.rs:82-107, f64, a box
+                                     whose clipped interval is a single point is culled); only the order of a node's two children
+                                     follows the ray (the child on the near side of the node's split axis first).  Slower than the
+                                     conservative 4-wide traversal, which also enters boxes the ray merely touches at an edge or
+                                     corner and can so report a hit the reference never tests (see RT_HIT_ORDERED). */
 
 /* Random numbers drawn inside traversal (constant_medium.rs:90) come from the
  * counter-based stream (seed, stream 2, ray index); see rt_rng_uniform. */

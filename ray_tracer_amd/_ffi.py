@@ -33,6 +33,7 @@ RT_REF_NONE = 0xFFFFFFFF
 RT_HIT_REFERENCE_ORDER = 0
 RT_HIT_ORDERED = 1
 RT_HIT_COUNTERS = 2
+RT_HIT_EXACT_CULL = 4
 RT_NOALLOC_MAX_RAYS = 1 << 24
 
 _d3 = C.c_double * 3

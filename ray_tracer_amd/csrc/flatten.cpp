@@ -154,7 +154,7 @@ uint32_t build_bvh(std::vector<Item>& items, size_t start, size_t end, DNode* no
         widen(nodes[left_at].bounds, wn.lb);
         widen(nodes[right_at].bounds, wn.rb);
     }
-    n.flags = medium ? 1u : 0u;
+    n.flags = (medium ? 1u : 0u) | ((uint32_t)axis << 1); // bits 1-2: the axis this node's objects were sorted along (bvh.rs:32)
     wn.left = n.left; wn.right = n.right;
     wn.meta = (medium ? 1u : 0u) | (n.left == n.right ? 2u : 0u);
     return medium;
@@ -736,6 +736,24 @@ struct Flattener {
         return ratio_n ? ratio_sum / (double)ratio_n : 1.0;
     }
 
+    // Stack entries the ordered traversal can need below 4-wide node `q`: up to (children - 1) siblings stay deferred
+    // while one child is walked, and that child is another 4-wide node or a leaf with a need of its own (a list pushes
+    // its continuation, an instance its restore entry, and what is below them goes on top of that).
+    std::vector<int32_t> need_wide_memo;
+    int32_t need_wide(uint32_t q) {
+        if (need_wide_memo.size() < f.qnodes.size()) need_wide_memo.resize(f.qnodes.size(), -1);
+        if (need_wide_memo[q] >= 0) return need_wide_memo[q];
+        int32_t n = 0, deepest = 0;
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t c = f.qnodes[q].child[j];
+            if (c == RT_REF_NONE) continue;
+            ++n;
+            if (RT_REF_KIND(c) == REF_QNODE) deepest = std::max(deepest, need_wide(RT_REF_INDEX(c)));
+            else if (RT_REF_KIND(c) != REF_QUADS) deepest = std::max(deepest, need(c)); // a run of quads is tested in place
+        }
+        return need_wide_memo[q] = std::max(0, n - 1) + deepest;
+    }
+
     // Stack entries a traversal starting at `ref` can need.
     int32_t need(uint32_t ref) {
         uint32_t kind = RT_REF_KIND(ref), idx = RT_REF_INDEX(ref);
@@ -747,7 +765,7 @@ struct Flattener {
             int32_t r;
             if (n.left == n.right && !(n.flags & 1u)) r = l; // the duplicate child is not pushed
             else r = std::max(1 + l, need(n.right));
-            if (f.wnodes[idx].qroot) r = std::max(r, need_q[idx]); // ordered traversal enters the 4-wide copy here
+            if (f.wnodes[idx].qroot) r = std::max(r, need_wide(f.wnodes[idx].qroot - 1)); // ordered traversal enters the 4-wide copy here
             need_node[idx] = r;
             return r;
         }
@@ -865,6 +883,7 @@ struct Flattener {
             // binary levels): it keeps the binary nodes; the dedicated kernel has its own spilling stack
             for (uint32_t root : bvh_roots) f.wnodes[root].qroot = 0;
             need_node.assign(f.nodes.size(), -1);
+            need_wide_memo.assign(f.qnodes.size(), -1);
             f.max_stack = (uint32_t)need(f.world) + 1;
         }
         if (f.max_stack > (uint32_t)STACK_MAX) return fail(RT_E_TOO_LARGE, "scene needs a deeper traversal stack than the kernels carry (32 entries)");

@@ -144,7 +144,8 @@ struct WaveWork {
 // MEDIA = false: the scene holds no constant medium; the nested boundary queries and the random draw are compiled out.
 template <bool COUNT, bool ORDERED, bool MEDIA>
 __global__ __launch_bounds__(BLOCK) void closest_hit_kernel(DScene S, rt_ray_batch rays, unsigned long long n, rt_hit_batch hits,
-                                                            int32_t* hit_ctx, unsigned long long seed, unsigned long long* counters, int rest_only) {
+                                                            int32_t* hit_ctx, unsigned long long seed, unsigned long long* counters, int rest_only,
+                                                            int axis_order) {
     __shared__ uint32_t s_stack[STACK_MAX * BLOCK];
     uint32_t* stk = s_stack + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(BLOCK) void closest_hit_kernel(DScene S, rt_ray_bat
                 if (first_hit != RT_REF_NONE) { b.t = hits.t[i]; b.ref = first_hit; }
                 root = S.world_rest;
             }
-            traverse<MEDIA, COUNT, ORDERED>(S, root, r, 0, w, time, tmin, b, stk, 0, &g, nn, np);
+            traverse<MEDIA, COUNT, ORDERED>(S, root, r, 0, w, time, tmin, b, stk, 0, &g, nn, np, axis_order != 0);
             // (t, what was hit, in which transform context): finalize_hits_kernel completes the record in a pass of
             // its own, which keeps the record arithmetic (acos, atan2, the transform unwinding) out of this
             // kernel's register budget
@@ -825,7 +826,9 @@ int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit
     int blocks = (int)std::min<uint64_t>((uint64_t)s->grid_blocks, (waves + (BLOCK / 64) - 1) / (BLOCK / 64));
     hipEvent_t* const ev = s->ev_hit[s->hit_launches % HIT_RING]; // start, traversal start, traversal end, end
     HIP_TRY(hipEventRecord(ev[0], st));
-    const bool count = flags & RT_HIT_COUNTERS, ordered = flags & RT_HIT_ORDERED;
+    // RT_HIT_ORDERED | RT_HIT_EXACT_CULL: the exact binary nodes, children ordered by the split axis (general kernel)
+    const bool exact_cull = (flags & RT_HIT_ORDERED) && (flags & RT_HIT_EXACT_CULL);
+    const bool count = flags & RT_HIT_COUNTERS, ordered = (flags & RT_HIT_ORDERED) && !exact_cull;
     const Tuning& tn = s->tune;
     if (ordered && s->flat.fast_root != RT_REF_NONE && !s->flat.fast_partial) {
         // the world is one BVH over primitives: dedicated traversal kernel + one pass that completes the records
@@ -886,7 +889,7 @@ int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit
     HIP_TRY(hipEventRecord(ev[1], st));
     auto launch = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3(blocks), dim3(BLOCK), 0, st, s->dev, *rays, (unsigned long long)n, *hits, hit_ctx, (unsigned long long)seed, s->d_counters,
-                           split ? 1 : 0);
+                           split ? 1 : 0, exact_cull ? 1 : 0);
     };
     if (s->flat.has_medium) {
         if (count && ordered) launch(closest_hit_kernel<true, true, true>);

@@ -162,10 +162,13 @@ __shared__ uint32_t s_lane_iters[256]; // loop iterations of each lane's current
 #define RT_STEP_END(k) do { } while (0)
 #endif
 
+// axis_order (exact nodes only): enter the child on the ray's near side of the node's split axis first.  Every box is
+// still tested by slab_test exactly as the reference does; only the order of two siblings changes, which can change
+// nothing but which of several primitives hit at exactly equal t is reported.
 template <bool TOP, bool COUNT, bool ORDERED, bool WAVE_LISTS = true, bool KEEP_ENTRY_RAY = WAVE_LISTS>
 __device__ __forceinline__ void traverse(const DScene& S, uint32_t root, RayD ray, int32_t ctx, const WorldRay& w,
                                          double time, double tmin, Best& best, uint32_t* stk, int sp0, Rng* rng,
-                                         uint32_t& n_nodes, uint32_t& n_prims) {
+                                         uint32_t& n_nodes, uint32_t& n_prims, bool axis_order = false) {
     int sp = sp0;
     uint32_t cur = root;
     const RayD entry_ray = ray;
@@ -253,8 +256,14 @@ __device__ __forceinline__ void traverse(const DScene& S, uint32_t root, RayD ra
                 // A one-object span stores the object as both children (bvh.rs:41-44).  Testing it
                 // a second time cannot change the record unless it draws random numbers, so the
                 // duplicate is visited only when the subtree holds a constant medium.
-                if (n.right != n.left || (n.flags & 1u)) { stk[sp * BLOCK] = n.right; ++sp; }
-                cur = n.left;
+                uint32_t first = n.left, second = n.right;
+                if (axis_order && !(n.flags & 1u)) { // a subtree with a medium keeps the reference order (its random draws)
+                    const uint32_t axis = (n.flags >> 1) & 3u;
+                    const double da = axis == 0u ? ray.dx : (axis == 1u ? ray.dy : ray.dz);
+                    if (da < 0.0) { first = n.right; second = n.left; }
+                }
+                if (n.right != n.left || (n.flags & 1u)) { stk[sp * BLOCK] = second; ++sp; }
+                cur = first;
                 pop = false;
             }
             RT_STEP_END(1);
@@ -383,7 +392,7 @@ __device__ __forceinline__ void traverse(const DScene& S, uint32_t root, RayD ra
                 for (int pass = 0; pass < 2 && ok; ++pass) {
                     Best b; b.t = D_INF; b.ref = RT_REF_NONE; b.ctx = 0;
                     double lo = pass == 0 ? -D_INF : t1 + 0.0001; // Interval::UNIVERSE, then [rec1.t + 0.0001, inf)
-                    traverse<false, COUNT, ORDERED, WAVE_LISTS, KEEP_ENTRY_RAY>(S, m.boundary, ray, ctx, w, time, lo, b, stk, sp, nullptr, n_nodes, n_prims);
+                    traverse<false, COUNT, ORDERED, WAVE_LISTS, KEEP_ENTRY_RAY>(S, m.boundary, ray, ctx, w, time, lo, b, stk, sp, nullptr, n_nodes, n_prims, axis_order);
                     if (b.ref == RT_REF_NONE) ok = false;
                     else if (pass == 0) t1 = b.t; else t2 = b.t;
                 }

@@ -196,6 +196,13 @@ def test_ordered_traversal_matches_reference_order():
         o3, d3, tm3 = rays_for([b[k] for k in range(6)] if np.isfinite(b[0]) and abs(b[0]) < 1e4 else [-200, 600, 0, 560, -200, 600],
                                40000, seed=23, spread=0.05)
         compare(desc, o3, d3, time=tm3, seed=9, min_hits=3000, flags=F.RT_HIT_ORDERED)
+    # the exact-box variant of the ordered traversal (children ordered by the split axis), incl. media and instances
+    for build in (lambda: scenes.book2_final(seed=0), scenes.cornell_smoke, scenes.cornell_box):
+        world, lights, cam = build()
+        desc = rt.SceneDesc.from_world(world, lights)
+        o3, d3, tm3 = rays_for([-200, 600, 0, 560, -200, 600], 30000, seed=24, spread=0.05)
+        compare(desc, o3, d3, time=tm3, seed=9, min_hits=3000, flags=F.RT_HIT_ORDERED | F.RT_HIT_EXACT_CULL)
+    compare(rt.SceneDesc.from_world(rt.Mesh(v, m)), o, d, min_hits=50000, flags=F.RT_HIT_ORDERED | F.RT_HIT_EXACT_CULL)
     # GPU-side counters: the ordered traversal must visit far fewer boxes than the reference order
     desc = rt.SceneDesc.from_world(rt.Mesh(v, m))
     g = rt.Scene(desc)
@@ -209,6 +216,10 @@ def test_ordered_traversal_matches_reference_order():
     g.closest_hit(o, d, flags=F.RT_HIT_COUNTERS | F.RT_HIT_ORDERED)
     fast = g.counters()
     assert fast.node_visits < 0.8 * ref.node_visits and fast.prim_tests < 0.5 * ref.prim_tests
+    g.reset_counters()
+    g.closest_hit(o, d, flags=F.RT_HIT_COUNTERS | F.RT_HIT_ORDERED | F.RT_HIT_EXACT_CULL)
+    cull = g.counters()
+    assert cull.node_visits < 0.7 * ref.node_visits, (cull.node_visits, ref.node_visits)
 
 
 def test_degenerate_batches():
@@ -284,3 +295,96 @@ def test_primitive_bvh_kernel_edge_cases():
         compare(desc, oo, dd, time=tm, tmin=tmin, tmax=tmax, min_hits=500, flags=F.RT_HIT_ORDERED)
         for n in (1, 2, 63, 64, 65, 129, 1000):
             compare(desc, oo[:n], dd[:n], min_hits=0, flags=F.RT_HIT_ORDERED)
+
+
+def test_deep_stacks_of_instanced_nested_lists():
+    """A BVH over Translate(RotateY(nested lists)) leaves: the ordered traversal keeps deferred siblings, restore
+    entries and list continuations on the LDS stack at the same time (up to 23 entries with 4-wide nodes here, 27
+    with the binary nodes the deeper scene falls back to).  Both visit orders against the oracle."""
+    from test_host_flatten import _instanced_leaf
+    m = rt.Lambertian(rt.Color(.5, .5, .5))
+    for n_leaves, nest in ((256, 2), (256, 8)):
+        lst = rt.HittableList()
+        for x in range(n_leaves):
+            lst.add(_instanced_leaf(m, x, nest))
+        desc = rt.SceneDesc.from_world(rt.HittableList.with_object(rt.BvhNode(lst)))
+        o, d, tm = scenes.incoherent_rays(30000, [0, 256, -0.5, 1.5, -0.5, 1.0], seed=61)
+        d[:, 0] *= 8.0  # along the row of instances: many boxes per ray
+        for flags in (0, F.RT_HIT_ORDERED):
+            compare(desc, o, d, time=tm, min_hits=3000, flags=flags)
+
+
+def _tangent_rays():
+    """Triangles, quads and spheres on integer coordinates in a BVH, and rays whose entry into a bounding box and
+    exit from it coincide exactly (every coordinate and parameter is a small dyadic rational, so the slab
+    arithmetic is exact): through box edges, through box corners, starting on box planes."""
+    m = rt.Lambertian(rt.Color(.5, .5, .5))
+    lst = rt.HittableList()
+    cells = []
+    for ix in range(4):
+        for iy in range(4):
+            for iz in range(2):
+                b = np.array([4.0 * ix, 4.0 * iy, 4.0 * iz])
+                cells.append(b)
+                k = (ix + iy + iz) % 3
+                if k == 0:   # triangle with its vertices on the corners of its box
+                    lst.add(rt.Triangle(rt.Point3(*b), rt.Point3(*(b + [2, 0, 1])), rt.Point3(*(b + [0, 2, 2])), m))
+                elif k == 1:  # tilted quad: corners on box corners
+                    lst.add(rt.Quad(rt.Point3(*b), rt.Vec3(2, 0, 1), rt.Vec3(0, 2, 0), m))
+                else:
+                    lst.add(rt.Sphere(rt.Point3(*(b + 1.0)), 1.0, m))
+    o, d = [], []
+    for b in cells:
+        lo, hi = b, b + np.array([2.0, 2.0, 2.0])
+        for corner in ((lo[0], lo[1], lo[2]), (hi[0], lo[1], lo[2] + 1.0), (lo[0], hi[1], hi[2]), (hi[0], hi[1], hi[2])):
+            c = np.array(corner)
+            for dirv in ((1, -1, 0), (-1, 1, 0), (1, 1, -1), (1, -1, 1), (-1, -1, 1), (1, 0, -1), (0, 1, 1), (2, -1, 0), (1, -2, 1)):
+                dv = np.array(dirv, float)
+                for back in (1.0, 2.0, 0.0):  # back = 0: the origin sits on the corner / edge itself
+                    o.append(c - back * dv); d.append(dv)
+        # through the middle of box edges, in the plane perpendicular to the edge
+        for e0, e1 in (((lo[0], lo[1]), (1, -1)), ((hi[0], lo[1]), (1, 1)), ((hi[0], hi[1]), (-1, 1)), ((lo[0], hi[1]), (1, 1))):
+            for z in (lo[2] + 0.5, lo[2] + 1.0):
+                o.append(np.array([e0[0] - 2.0 * e1[0], e0[1] - 2.0 * e1[1], z])); d.append(np.array([e1[0], e1[1], 0.0]))
+    return rt.SceneDesc.from_world(rt.BvhNode(lst)), np.array(o), np.array(d)
+
+
+def test_rays_tangent_to_boxes():
+    """aabb.rs:102 culls a box when the clipped interval is empty OR a single point (`ray_t.max <= ray_t.min`): a ray
+    that enters a box exactly where it leaves it (edge, corner) never reaches what is inside, even a primitive
+    that touches that very edge.  RT_HIT_REFERENCE_ORDER keeps that rule and must equal the oracle ray for ray.
+    RT_HIT_ORDERED tests conservative boxes (entry <= exit accepts) and therefore still tests such a primitive:
+    it may report a hit, geometrically on the primitive, where the reference reports none or a farther one.
+    That is a deviation beyond the tie rule, confined to rays whose box entry and exit coincide exactly; this
+    test pins it (which rays differ, and that every differing hit is real)."""
+    desc, o, d = _tangent_rays()
+    gpu, cpu = rt.Scene(desc), O.OracleScene(desc)
+    want = cpu.closest_hit(o, d)
+    exact = gpu.closest_hit(o, d, flags=F.RT_HIT_REFERENCE_ORDER)
+    assert np.array_equal(exact["prim"], want["prim"]) and np.array_equal(exact["t"], want["t"])
+    fast = gpu.closest_hit(o, d, flags=F.RT_HIT_ORDERED)
+    assert (want["prim"] != F.RT_REF_NONE).sum() > 200
+    differ = np.nonzero(fast["t"] != want["t"])[0]
+    # never a hit lost or pushed back: the conservative traversal only ever finds more
+    assert np.all(fast["t"][differ] < want["t"][differ])
+    for i in differ:  # every extra hit lies on its primitive, and the exact-box traversal of the same ray skipped a box there
+        p = o[i] + fast["t"][i] * d[i]
+        assert np.allclose(p, [fast["px"][i], fast["py"][i], fast["pz"][i]], rtol=0, atol=1e-12)
+        kind = int(fast["prim"][i]) >> 28
+        assert kind in (F.RT_REF_TRI, F.RT_REF_QUAD, F.RT_REF_SPHERE)
+        if kind == F.RT_REF_SPHERE:
+            s = desc.arrays["spheres"][int(fast["prim"][i]) & 0x0FFFFFFF]
+            assert abs(np.linalg.norm(p - s["center"]) - s["radius"]) < 1e-9
+        else:
+            assert 0.0 <= fast["u"][i] <= 1.0 and 0.0 <= fast["v"][i] <= 1.0
+    # the batch is built to provoke it (about a quarter of these rays); it vanishes once the rays are nudged off the edges
+    assert 0 < len(differ) <= 0.4 * len(o), len(differ)
+    # RT_HIT_EXACT_CULL: near-side-first order on the exact boxes, the reference's cull rule intact: same t as the oracle on
+    # every ray, the primitive differing only at exactly equal t
+    cull = gpu.closest_hit(o, d, flags=F.RT_HIT_ORDERED | F.RT_HIT_EXACT_CULL)
+    assert np.array_equal(cull["t"], want["t"])
+    assert np.mean(cull["prim"] != want["prim"]) < 0.05
+    o2 = o + 1e-3 * np.array([0.37, -0.21, 0.13])
+    a, b = gpu.closest_hit(o2, d, flags=F.RT_HIT_ORDERED), cpu.closest_hit(o2, d)
+    assert np.array_equal(a["t"], b["t"])
+    gpu.close()

@@ -310,3 +310,41 @@ def test_reference_side_binding_in_integration_md_covers_the_header():
         rust_fields = re.findall(r"pub ([a-z0-9_]+)\s*:", body)
         c_fields = [f[0] for f in getattr(F, name)._fields_]
         assert rust_fields == c_fields, (name, rust_fields, c_fields)
+
+
+def _instanced_leaf(m, x, nest):
+    """Translate(RotateY(list)) whose list is `nest` levels of two-member lists (inner list first, a sphere after
+    it): entering every level leaves a list continuation (two entries) on the traversal stack."""
+    inner = rt.box_new(rt.Point3(0, 0, 0), rt.Point3(0.5, 0.5, 0.5), m)
+    for _ in range(nest):
+        outer = rt.HittableList.with_object(inner)
+        outer.add(rt.Sphere(rt.Point3(0.25, 0.8, 0.25), 0.1, m))
+        inner = outer
+    return rt.Translate(rt.RotateY(inner, 15.0), rt.Vec3(float(x), 0.0, 0.0))
+
+
+def test_stack_need_counts_the_leaves_of_wide_nodes():
+    """The ordered traversal defers up to three siblings per 4-wide level and a leaf then adds its own entries
+    (an instance its restore entry, a list its continuation).  max_stack must cover the sum; when the 4-wide form
+    needs more than the 32 entries the kernels carry the scene keeps its binary nodes, and beyond that it is
+    rejected instead of overrunning the LDS stack."""
+    m = rt.Lambertian(rt.Color(.5, .5, .5))
+
+    def scene(n_leaves, nest):
+        lst = rt.HittableList()
+        for x in range(n_leaves):
+            lst.add(_instanced_leaf(m, x, nest))
+        return rt.HittableList.with_object(rt.BvhNode(lst))
+
+    # 256 leaves: binary depth 8 = four 4-wide levels (3 deferred siblings each); leaf: restore entry + nest * 2
+    info = rt.Scene(scene(256, 2), host_only=True).info()
+    assert info.max_stack >= 3 * 4 + 1 + 2 * 2 + 1
+    wide = rt.Scene(scene(256, 2), host_only=True).wide_nodes()
+    assert len(wide) > 0
+    # 8 levels of lists: 12 + 1 + 16 entries and more exceed 32 with 4-wide nodes, the binary form (8 + 1 + 16 ...) fits
+    deep = rt.Scene(scene(256, 8), host_only=True)
+    assert 8 + 1 + 2 * 8 + 1 <= deep.info().max_stack <= 32
+    # 13 levels: no form fits
+    with pytest.raises(F.RtError) as e:
+        rt.Scene(scene(256, 13), host_only=True)
+    assert e.value.code == F.RT_E_TOO_LARGE
