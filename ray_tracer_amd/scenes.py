@@ -192,6 +192,30 @@ def cornell_box(image_width: int = 600, samples_per_pixel: int = 1000, max_depth
     return world, lights, cam
 
 
+def cornell_two_blocks(image_width: int = 600, samples_per_pixel: int = 200, max_depth: int = 50) -> SceneTuple:
+    """The "standard Cornell box scene" of Book 2 (the revision of main.rs that rendered output33.ppm, see
+    time_record.txt:19): the room of cornell_box with two rotated blocks and no glass sphere, rendered before the
+    light list existed (material PDF alone: lights = None)."""
+    world = HittableList()
+    red = Lambertian(Color(0.65, 0.05, 0.05))
+    white = Lambertian(Color(0.73, 0.73, 0.73))
+    green = Lambertian(Color(0.12, 0.45, 0.15))
+    light = DiffuseLight.from_color(Color(15.0, 15.0, 15.0))
+    world.add(Quad(Point3(555.0, 0.0, 0.0), Vec3(0.0, 555.0, 0.0), Vec3(0.0, 0.0, 555.0), green))
+    world.add(Quad(Point3(0.0, 0.0, 0.0), Vec3(0.0, 555.0, 0.0), Vec3(0.0, 0.0, 555.0), red))
+    world.add(Quad(Point3(343.0, 554.0, 332.0), Vec3(-130.0, 0.0, 0.0), Vec3(0.0, 0.0, -105.0), light))
+    world.add(Quad(Point3(0.0, 0.0, 0.0), Vec3(555.0, 0.0, 0.0), Vec3(0.0, 0.0, 555.0), white))
+    world.add(Quad(Point3(555.0, 555.0, 555.0), Vec3(-555.0, 0.0, 0.0), Vec3(0.0, 0.0, -555.0), white))
+    world.add(Quad(Point3(0.0, 0.0, 555.0), Vec3(555.0, 0.0, 0.0), Vec3(0.0, 555.0, 0.0), white))
+    box1: Hittable = box_new(Point3(0.0, 0.0, 0.0), Point3(165.0, 330.0, 165.0), white)
+    world.add(Translate(RotateY(box1, 15.0), Vec3(265.0, 0.0, 295.0)))
+    box2: Hittable = box_new(Point3(0.0, 0.0, 0.0), Point3(165.0, 165.0, 165.0), white)
+    world.add(Translate(RotateY(box2, -18.0), Vec3(130.0, 0.0, 65.0)))
+    cam = _cornell_camera(samples_per_pixel)
+    cam.image_width, cam.max_depth = image_width, max_depth
+    return world, None, cam
+
+
 def cornell_smoke(image_width: int = 600, samples_per_pixel: int = 200, max_depth: int = 50) -> SceneTuple:
     """cornell_smoke (main.rs:553-649): two constant media bounded by instanced boxes, inside a BVH."""
     world = HittableList()

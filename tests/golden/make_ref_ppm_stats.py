@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Statistics of the rendered images the reference ships (its only result artefacts): overall mean RGB and the
+means of an 8 x 8 grid of blocks, of output28.ppm (quads, 400 x 400), output33.ppm (standard Cornell box,
+600 x 600), output34.ppm (Cornell box with blocks of smoke) and output35.ppm (Book-2 final scene, simple settings, 400 x 400).  Only numbers derived from the
+pixel data are written (tests/golden/ref_ppm_stats.json); run in the build container, where /root/reference
+exists:   python tests/golden/make_ref_ppm_stats.py
+
+The files are P3 text; from output16.ppm on a trailer line with the render time follows the pixels (the reference
+prints its timer to the same stdout), which is dropped here.  The images were rendered by earlier revisions of
+the reference (before light sampling) with thread_rng, so they pin the look of the scenes and of the material-PDF
+estimator, not bits."""
+import json
+import os
+
+import numpy as np
+
+REF = "/root/reference"
+FILES = {"quads": "output28.ppm", "cornell_two_blocks": "output33.ppm", "cornell_smoke": "output34.ppm", "book2_final_simple": "output35.ppm"}
+
+
+def read_p3(path):
+    with open(path, "rb") as fh:
+        tokens = fh.read().split()
+    assert tokens[0] == b"P3"
+    w, h, maxv = int(tokens[1]), int(tokens[2]), int(tokens[3])
+    vals = np.array([int(t) for t in tokens[4:4 + 3 * w * h]], dtype=np.float64)
+    assert len(vals) == 3 * w * h and maxv == 255
+    return vals.reshape(h, w, 3)
+
+
+def stats(img, grid=8):
+    h, w, _ = img.shape
+    blocks = [[img[h * j // grid:h * (j + 1) // grid, w * i // grid:w * (i + 1) // grid].mean(axis=(0, 1)).round(3).tolist()
+               for i in range(grid)] for j in range(grid)]
+    return {"width": w, "height": h, "mean_rgb": img.mean(axis=(0, 1)).round(3).tolist(), "block_means": blocks}
+
+
+if __name__ == "__main__":
+    out = {name: dict(stats(read_p3(os.path.join(REF, f))), source=f) for name, f in FILES.items()}
+    dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_ppm_stats.json")
+    json.dump(out, open(dst, "w"), indent=1)
+    for k, v in out.items():
+        print(k, v["width"], v["height"], v["mean_rgb"])
