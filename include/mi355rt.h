@@ -223,6 +223,16 @@ int rt_scene_get_wide_nodes(const rt_scene* scene, uint64_t first, uint64_t coun
 /* bounding_box() of an object of the description (hittable.rs:50), as 6 doubles. */
 int rt_scene_object_bounds(const rt_scene* scene, int32_t object, double out[6]);
 
+/* Replaces `tobj::load_obj(path, {triangulate, single_index})` and the vertex loops of Mesh::from_obj
+ * (mesh.rs:101-158) and ObjModel::load (obj_loader.rs:21-83): reads a Wavefront OBJ file into triangles.
+ * Positions are parsed to f32 and widened to f64 as tobj + mesh.rs:137-153 do; faces are fan-triangulated;
+ * all models of the file are concatenated.  scale_offset = NULL keeps the positions (Mesh::from_obj);
+ * otherwise {scale, offset x, y, z}: every component becomes p * scale + offset in f64 (obj_loader.rs:51-67).
+ * The array is allocated by the library (host memory); release it with rt_obj_free.  Use the triangles as
+ * RT_OBJ_BVH + RT_CHILD_TRIANGLES (Mesh) or RT_OBJ_OBJMODEL (ObjModel) of a scene description. */
+int  rt_obj_load(const char* path, const double* scale_offset, int32_t mat, rt_triangle** triangles, uint64_t* n_triangles);
+void rt_obj_free(rt_triangle* triangles);
+
 /* ------------------------------------------------------------- closest hit
  * Batched form of `world.hit(&ray, Interval::new(tmin, tmax), &mut rec)`
  * (hittable.rs:49; caller camera.rs:258).  Structure-of-arrays, f64. */

@@ -1025,6 +1025,8 @@ int need_device(rt_scene* s) {
 
 } // namespace
 
+namespace rt { int set_last_error(int code, const std::string& message) { return set_err(code, message); } } // for obj.cpp
+
 extern "C" {
 
 const char* rt_last_error(void) { return g_err.c_str(); }

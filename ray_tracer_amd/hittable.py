@@ -108,8 +108,8 @@ class Mesh(TriangleSet):  # mesh.rs:95-183: BVH over the triangles of an OBJ fil
 
     @staticmethod
     def from_obj(path: str, material: Material) -> "Mesh":  # mesh.rs:101-167
-        from .obj_loader import load_obj_triangles
-        return Mesh(load_obj_triangles(path), material)
+        from .obj_loader import load_obj
+        return Mesh(load_obj(path), material)
 
 
 class ObjModel(TriangleSet):  # obj_loader.rs:13-106: scaled + offset triangles, linear scan
@@ -118,10 +118,8 @@ class ObjModel(TriangleSet):  # obj_loader.rs:13-106: scaled + offset triangles,
 
     @staticmethod
     def load(path: str, material: Material, scale: float, offset: Point3) -> "ObjModel":  # obj_loader.rs:21-83
-        from .obj_loader import load_obj_triangles
-        v = load_obj_triangles(path)
-        off = np.array([offset.x(), offset.y(), offset.z()], dtype=np.float64)
-        return ObjModel(v * float(scale) + off, material)  # p * scale + offset per component (obj_loader.rs:51-67)
+        from .obj_loader import load_obj
+        return ObjModel(load_obj(path, scale, (offset.x(), offset.y(), offset.z())), material)  # p * scale + offset per component (obj_loader.rs:51-67)
 
 
 class SphereSet(Hittable):

@@ -9,11 +9,37 @@ is unpinned: the reference ships no model file.
 """
 from __future__ import annotations
 
+import ctypes as C
+from typing import Optional, Sequence
+
 import numpy as np
 
 
+def load_obj(path: str, scale: Optional[float] = None, offset: Optional[Sequence[float]] = None) -> np.ndarray:
+    """(N, 3, 3) float64 triangle vertices read by the library's own reader (rt_obj_load).  Without `scale` the
+    positions are kept as Mesh::from_obj keeps them (mesh.rs:137-153); with it every component becomes
+    p * scale + offset in f64, as ObjModel::load computes it (obj_loader.rs:51-67)."""
+    from . import _ffi as F
+    tris = C.POINTER(F.rt_triangle)()
+    n = C.c_uint64()
+    so = None
+    if scale is not None:
+        off = (0.0, 0.0, 0.0) if offset is None else offset
+        so = (C.c_double * 4)(float(scale), float(off[0]), float(off[1]), float(off[2]))
+    F.check(F.lib.rt_obj_load(path.encode(), so, 0, C.byref(tris), C.byref(n)))
+    try:
+        if n.value == 0:
+            return np.zeros((0, 3, 3), dtype=np.float64)
+        raw = np.ctypeslib.as_array(C.cast(tris, C.POINTER(C.c_double)), shape=(n.value, 10))  # 9 doubles + mat/_pad
+        return np.ascontiguousarray(raw[:, :9].reshape(n.value, 3, 3).copy())
+    finally:
+        F.lib.rt_obj_free(tris)
+
+
 def load_obj_triangles(path: str) -> np.ndarray:
-    """Returns an (N, 3, 3) float64 array of triangle vertices."""
+    """The same reader in Python, kept as an independent cross-check of rt_obj_load in the tests (it parses decimals
+    to f64 and then rounds to f32, which can differ from a direct decimal -> f32 conversion in the last bit of a
+    coordinate in rare cases).  Returns an (N, 3, 3) float64 array of triangle vertices."""
     positions = []
     faces = []
     with open(path, "r", encoding="utf-8", errors="replace") as fh:

@@ -388,3 +388,25 @@ def test_rays_tangent_to_boxes():
     a, b = gpu.closest_hit(o2, d, flags=F.RT_HIT_ORDERED), cpu.closest_hit(o2, d)
     assert np.array_equal(a["t"], b["t"])
     gpu.close()
+
+
+def test_obj_file_to_gpu(tmp_path):
+    """File -> rt_obj_load -> scene description -> HIP kernels, against the oracle on the same description:
+    Mesh::from_obj (BVH over the file's triangles, mesh.rs:101-167) in both visit orders, and ObjModel::load with
+    scale and offset (linear scan, obj_loader.rs:21-101)."""
+    from test_host_flatten import _write_obj
+    p = str(tmp_path / "lumpy.obj")
+    _write_obj(p, np.random.default_rng(3), n_u=40, n_v=24)
+    m = rt.Metal(rt.Color(.8, .8, .9), 0.0)
+    mesh = rt.Mesh.from_obj(p, m)
+    assert len(mesh.vertices) > 2000
+    o, d, tm = scenes.incoherent_rays(40000, [-1.3, 1.3, -1.3, 1.3, -1.3, 1.3], seed=71)
+    for flags in (0, F.RT_HIT_ORDERED, F.RT_HIT_ORDERED | F.RT_HIT_EXACT_CULL):
+        compare(rt.SceneDesc.from_world(mesh), o, d, min_hits=15000, flags=flags)
+    model = rt.ObjModel.load(p, m, 2.5, rt.Point3(10.0, -3.0, 0.125))
+    o2 = o[:6000] * 2.5 + np.array([10.0, -3.0, 0.125])
+    compare(rt.SceneDesc.from_world(model), o2, d[:6000], min_hits=2000)
+    # the model inside a scene graph: instanced, next to other members
+    world = rt.HittableList.with_object(rt.Translate(rt.RotateY(mesh, 30.0), rt.Vec3(0.5, 0.0, 0.0)))
+    world.add(rt.Sphere(rt.Point3(0.0, -101.5, 0.0), 100.0, rt.Lambertian(rt.Color(.5, .5, .5))))
+    compare(rt.SceneDesc.from_world(world), o, d, min_hits=15000, flags=F.RT_HIT_ORDERED)

@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "mi355rt.h")).read()
-    declared = set(re.findall(r"^(?:int|double|const char\*)\s+(rt_[a-z0-9_]+)\s*\(", header, re.M))
+    declared = set(re.findall(r"^(?:int|void|double|const char\*)\s+(rt_[a-z0-9_]+)\s*\(", header, re.M))
     assert declared, "no declarations parsed"
     assert declared == set(F.PROTOTYPES), declared ^ set(F.PROTOTYPES)
     raw = C.CDLL(F.LIB_PATH)
@@ -301,7 +301,7 @@ def test_reference_side_binding_in_integration_md_covers_the_header():
     ctypes structs in the same order."""
     text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     header = open(os.path.join(ROOT, "include", "mi355rt.h")).read()
-    declared = set(re.findall(r"^(?:int|double|const char\*)\s+(rt_[a-z0-9_]+)\s*\(", header, re.M))
+    declared = set(re.findall(r"^(?:int|void|double|const char\*)\s+(rt_[a-z0-9_]+)\s*\(", header, re.M))
     rust_fns = set(re.findall(r"pub fn (rt_[a-z0-9_]+)\s*\(", text))
     assert rust_fns == declared, rust_fns ^ declared
     for name, body in re.findall(r"pub struct (rt_[a-z0-9_]+)\s*\{([^}]*)\}", text):
@@ -348,3 +348,68 @@ def test_stack_need_counts_the_leaves_of_wide_nodes():
     with pytest.raises(F.RtError) as e:
         rt.Scene(scene(256, 13), host_only=True)
     assert e.value.code == F.RT_E_TOO_LARGE
+
+
+def _write_obj(path, rng, n_u=14, n_v=9):
+    """A closed lumpy surface as an OBJ file exercising what a real asset can hold: decimal coordinates that are not
+    f32 values, quads and pentagon fans next to triangles, v / v/vt / v//vn / v/vt/vn corners, negative (relative)
+    indices, two groups, comments, blank lines, CRLF line ends, normals and texture coordinates to be skipped."""
+    lines = ["# written by the test suite", "o lumpy", ""]
+    verts = []
+    for j in range(n_v + 1):
+        for i in range(n_u):
+            th, ph = np.pi * j / n_v, 2 * np.pi * i / n_u
+            r = 1.0 + 0.15 * np.sin(3 * th) * np.cos(2 * ph)
+            verts.append((r * np.sin(th) * np.cos(ph), r * np.cos(th), r * np.sin(th) * np.sin(ph)))
+    for v in verts:
+        lines.append("v %.9f %.9f %.9f" % v)
+    lines += ["vt 0.5 0.5", "vn 0 1 0", "g upper"]
+    idx = lambda i, j: j * n_u + (i % n_u) + 1
+    forms = ("%d", "%d/1", "%d//1", "%d/1/1")
+    for j in range(n_v):
+        if j == n_v // 2:
+            lines.append("g lower\r")
+        for i in range(n_u):
+            a, b, c, d = idx(i, j), idx(i + 1, j), idx(i + 1, j + 1), idx(i, j + 1)
+            f = forms[(i + j) % 4]
+            if (i + j) % 3 == 0:   # a quad
+                lines.append("f " + " ".join(f % k for k in (a, b, c, d)))
+            elif (i + j) % 3 == 1:  # two triangles, the second with relative indices
+                lines.append("f " + " ".join(f % k for k in (a, b, c)))
+                lines.append("f " + " ".join(str(k - len(verts) - 1) for k in (a, c, d)))
+            else:                   # a pentagon: the quad with one more corner on an edge (a repeated vertex keeps it planar enough)
+                lines.append("f " + " ".join(f % k for k in (a, b, c, d, a)))
+    open(path, "w").write("\n".join(lines) + "\n")
+    return len(verts)
+
+
+def test_obj_file_through_the_c_abi(tmp_path):
+    """rt_obj_load (the library's reader, what Mesh::from_obj / ObjModel::load use here) against the independent
+    Python reader: same triangles from the same file; ObjModel's scale and offset applied per component in f64
+    (obj_loader.rs:51-67); errors reported, not thrown."""
+    from ray_tracer_amd.obj_loader import load_obj, load_obj_triangles
+    p = str(tmp_path / "lumpy.obj")
+    _write_obj(p, np.random.default_rng(3))
+    a, b = load_obj(p), load_obj_triangles(p)
+    assert a.shape == b.shape and a.shape[0] > 250 and np.array_equal(a, b)
+    assert np.array_equal(a, a.astype(np.float32).astype(np.float64))  # every coordinate is an f32 value (tobj stores f32)
+    s = load_obj(p, 2.5, (10.0, -3.0, 0.125))
+    assert np.array_equal(s, a * 2.5 + np.array([10.0, -3.0, 0.125]))
+    m = rt.Lambertian(rt.Color(.5, .5, .5))
+    mesh, model = rt.Mesh.from_obj(p, m), rt.ObjModel.load(p, m, 2.5, rt.Point3(10.0, -3.0, 0.125))
+    assert np.array_equal(mesh.vertices, a) and np.array_equal(model.vertices, s)
+    # bounding_box() of the ObjModel: from_points(min, max) over the transformed vertices (obj_loader.rs:103-105)
+    desc = rt.SceneDesc.from_world(model)
+    want = O.OracleScene(desc).object_bounds(desc.world)
+    assert np.array_equal(rt.Scene(desc, host_only=True).object_bounds(desc.world), want)
+    with pytest.raises(F.RtError) as e:
+        load_obj(str(tmp_path / "missing.obj"))
+    assert e.value.code == F.RT_E_INVALID and "cannot open" in e.value.message
+    bad = tmp_path / "bad.obj"
+    bad.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 7\n")
+    with pytest.raises(F.RtError) as e:
+        load_obj(str(bad))
+    assert e.value.code == F.RT_E_INVALID and "out of range" in e.value.message
+    empty = tmp_path / "empty.obj"
+    empty.write_text("# nothing\n")
+    assert load_obj(str(empty)).shape == (0, 3, 3)
