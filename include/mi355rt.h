@@ -298,7 +298,10 @@ typedef struct rt_camera {
     int32_t image_width;
     int32_t samples_per_pixel;
     int32_t max_depth;
-    int32_t _pad;
+    int32_t russian_roulette; /* 0 (the reference at HEAD): off.  1: the termination rule of the reference's history
+                                 (camera.rs:407-416, time_record.txt:23-24): at a bounce sampled through a PDF the path
+                                 goes on with probability clamp(max(attenuation), 0.1, 1) and otherwise returns its
+                                 emission; as written there, survivors are not re-weighted. */
     double  background[3];
     double  vfov;
     double  lookfrom[3];

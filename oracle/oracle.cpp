@@ -1045,6 +1045,11 @@ struct Camera { // camera.rs:15-339
         }
         Ray scattered(rec.p, scattered_dir, r.tm);
         double scattering_pdf = rec.mat->scattering_pdf(r, rec, scattered);
+        if (c.russian_roulette) { // the rule of the reference's history (camera.rs:407-416): no re-weighting of survivors
+            double p = std::fmax(std::fmax(srec.attenuation.x, srec.attenuation.y), srec.attenuation.z);
+            p = p < 0.1 ? 0.1 : (p > 1.0 ? 1.0 : p); // f64::clamp(0.1, 1.0)
+            if (random_double() >= p) return color_from_emission;
+        }
         Color color_from_scatter = (srec.attenuation * scattering_pdf * ray_color(scattered, depth - 1, world, lights)) / pdf_value;
         return color_from_emission + color_from_scatter;
     }

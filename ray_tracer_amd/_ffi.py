@@ -116,7 +116,7 @@ class rt_hit_batch(C.Structure):
 
 class rt_camera(C.Structure):
     _fields_ = [("aspect_ratio", C.c_double), ("image_width", C.c_int32), ("samples_per_pixel", C.c_int32),
-                ("max_depth", C.c_int32), ("_pad", C.c_int32), ("background", _d3), ("vfov", C.c_double),
+                ("max_depth", C.c_int32), ("russian_roulette", C.c_int32), ("background", _d3), ("vfov", C.c_double),
                 ("lookfrom", _d3), ("lookat", _d3), ("vup", _d3), ("defocus_angle", C.c_double),
                 ("focus_dist", C.c_double)]
 

@@ -36,6 +36,7 @@ class Camera:
         self.image_width = 100
         self.samples_per_pixel = 10
         self.max_depth = 10
+        self.russian_roulette = False  # the termination rule of the reference's history (camera.rs:407-416); off at HEAD
         self.background = Color(0.0, 0.0, 0.0)
         self.vfov = 90.0
         self.lookfrom = Point3(0.0, 0.0, 0.0)
@@ -48,6 +49,7 @@ class Camera:
         c = F.rt_camera()
         c.aspect_ratio, c.image_width = float(self.aspect_ratio), int(self.image_width)
         c.samples_per_pixel, c.max_depth = int(self.samples_per_pixel), int(self.max_depth)
+        c.russian_roulette = 1 if self.russian_roulette else 0
         c.background = (C.c_double * 3)(*self.background)
         c.vfov = float(self.vfov)
         c.lookfrom = (C.c_double * 3)(*self.lookfrom)

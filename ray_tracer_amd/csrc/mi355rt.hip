@@ -52,7 +52,7 @@ struct CamD { // Camera after initialize() (camera.rs:30-42)
     double defocus_angle;
     double background[3];
     int32_t image_width;
-    int32_t _pad;
+    int32_t russian_roulette;
 };
 
 // One path = one 128-byte line in HBM.  The queues permute the paths after the first bounce, so every
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(DScene S, CamD cam, PathSt
                     Rng g{seed, 0u, (uint32_t)(j * cam.image_width + i), (uint32_t)(bg.sample0 + (int32_t)s_local), rec->rng_index};
                     D3 ray_dir = d3(wr.dx, wr.dy, wr.dz);
                     D3 nd;
-                    alive = shade_hit<TEXTURES>(S, h, ray_dir, g, beta, L, nd);
+                    alive = shade_hit<TEXTURES>(S, h, ray_dir, g, beta, L, nd, cam.russian_roulette != 0);
                     RT_PHASE(2);
                     if (alive) {
                         if (last_bounce) { // the next ray_color call has depth 0 and returns black (camera.rs:252-254)
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(BLOCK) void tail_kernel(DScene S, CamD cam, PathSta
             finalize(S, r, time, b, h, TEXTURES && S.uses_uv != 0u);
             D3 ray_dir = d3(r.dx, r.dy, r.dz);
             D3 nd;
-            if (!shade_hit<TEXTURES>(S, h, ray_dir, g, beta, L, nd)) break;
+            if (!shade_hit<TEXTURES>(S, h, ray_dir, g, beta, L, nd, cam.russian_roulette != 0)) break;
             if (bounce == max_depth - 1) { // the next ray_color call has depth 0 and returns black (camera.rs:252-254)
                 L = L + beta * d3(0.0, 0.0, 0.0);
                 break;
@@ -921,6 +921,7 @@ int render_impl(rt_scene* s, const rt_camera* cam, uint64_t seed, const rt_work*
     cd.defocus_angle = cam->defocus_angle;
     cd.background[0] = cam->background[0]; cd.background[1] = cam->background[1]; cd.background[2] = cam->background[2];
     cd.image_width = cam->image_width;
+    cd.russian_roulette = cam->russian_roulette;
     rt_work w;
     const int32_t nstrata = cd.d.sqrt_spp * cd.d.sqrt_spp;
     if (work) w = *work;

@@ -206,7 +206,7 @@ RT_DEV D3 sample_lobe(const LobeSample& lobe, Rng& g) {
 // Returns true when the path continues from the hit point h.p in direction next_d (every scattering material
 // starts the scattered ray at rec.p: material.rs:100, 153, 214, 291); beta/L are updated in place.
 template <bool TEXTURES>
-RT_DEV bool shade_hit(const DScene& S, const HitRec& h, D3 ray_dir, Rng& g, D3& beta, D3& L, D3& next_d) {
+RT_DEV bool shade_hit(const DScene& S, const HitRec& h, D3 ray_dir, Rng& g, D3& beta, D3& L, D3& next_d, bool russian_roulette) {
     const DMaterial m = S.materials[h.mat];
     if (m.kind == RT_MAT_DIFFUSE_LIGHT) { // material.rs:237-256: emits on the front face, never scatters
         // The back face emits black, and black still goes through the product: a path whose throughput is NaN
@@ -270,6 +270,16 @@ RT_DEV bool shade_hit(const DScene& S, const HitRec& h, D3 ray_dir, Rng& g, D3& 
         scattering_pdf = cos_theta < 0.0 ? 0.0 : cos_theta / D_PI;
     } else {
         scattering_pdf = 1.0 / (4.0 * D_PI);
+    }
+    if (russian_roulette) { // the rule of the reference's history (camera.rs:407-416): no re-weighting of survivors
+        double p = fmax(fmax(attenuation.x, attenuation.y), attenuation.z);
+        p = p < 0.1 ? 0.1 : (p > 1.0 ? 1.0 : p);
+        if (g.next() >= p) {
+            // the recursion returns this vertex's emission (black for these materials) and its callers still multiply
+            // it by their factors: a NaN or infinite throughput must turn the sample into NaN here as it does there
+            L = L + beta * d3(0.0, 0.0, 0.0);
+            return false;
+        }
     }
     beta = (beta * (attenuation * scattering_pdf)) / pdf_value; // camera.rs:326-336
     next_d = dir;

@@ -54,6 +54,31 @@ def assert_same_ray_count(gpu_rays, oracle_rays):
     assert abs(int(gpu_rays) - int(oracle_rays)) <= max(2, int(1e-4 * oracle_rays)), (gpu_rays, oracle_rays)
 
 
+def test_russian_roulette_switch():
+    """rt_camera.russian_roulette = 1: the termination rule of the reference's history (camera.rs:407-416), in the
+    oracle and on the device alike -- same frames, same number of world.hit queries, fewer of them than without
+    the rule (the reference's own timings: 11756 s -> 2793 s for the Book-2 final scene, time_record.txt:22-23)."""
+    for build, width, spp, depth in ((scenes.cornell_box, 64, 64, 50), (scenes.book2_final, 48, 16, 40), (scenes.cornell_smoke, 48, 36, 50),
+                                     (scenes.book1_final, 64, 9, 50)):
+        world, lights, cam = build()
+        cam.image_width, cam.samples_per_pixel, cam.max_depth = width, spp, depth
+        desc = rt.SceneDesc.from_world(world, lights)
+        gpu, cpu = rt.Scene(desc), O.OracleScene(desc)
+        plain = gpu.render(cam.to_struct(), seed=2)
+        rays_plain = gpu.counters().render_rays
+        cam.russian_roulette = True
+        c = cam.to_struct()
+        assert c.russian_roulette == 1
+        stats = {}
+        gpu.reset_counters()
+        a, b = gpu.render(c, seed=2), cpu.render(c, seed=2, stats=stats)
+        check(c, a, b)
+        assert_same_ray_count(gpu.counters().render_rays, stats["rays"])
+        assert gpu.counters().render_rays < 0.9 * rays_plain, (build.__name__, gpu.counters().render_rays, rays_plain)
+        assert not np.array_equal(np.nan_to_num(a), np.nan_to_num(plain))
+        gpu.close()
+
+
 def test_cornell_box_mixture_pdf():
     cam, c, a, b, stats, ctr, gpu = render_both(scenes.cornell_box, 64, 64, 50)
     check(c, a, b)
