@@ -71,7 +71,7 @@ inline bool box_has_nan(const Box& a) {
     return false;
 }
 
-struct Item { Box box; uint32_t ref; uint32_t medium; };
+typedef BuildItem Item;
 
 // f64 -> f32 rounded away from the box interior, so the f32 box contains the f64 box.
 inline float f32_down(double x) { float f = (float)x; if ((double)f > x) f = std::nextafterf(f, -std::numeric_limits<float>::infinity()); return f; }
@@ -163,6 +163,20 @@ uint32_t build_bvh(std::vector<Item>& items, size_t start, size_t end, DNode* no
 struct Flattener {
     const rt_scene_desc* d;
     FlatScene& f;
+    uint64_t device_bvh_min = 0;
+    // BvhNode::new over `items` into nodes[base ...]: on the device when the BVH is large enough and holds no medium
+    int build_nodes(std::vector<Item>& items, uint64_t base) {
+        bool medium = false;
+        for (const Item& it : items) medium = medium || it.medium;
+        if (device_bvh_min && items.size() >= device_bvh_min && !medium) {
+            std::string e;
+            const int rc = build_bvh_device(items.data(), items.size(), base, f.nodes.data() + base, f.wnodes.data() + base, e);
+            if (rc) return fail(rc, "device BVH build: " + e);
+            return RT_OK;
+        }
+        build_bvh(items, 0, items.size(), f.nodes.data() + base, f.wnodes.data() + base, base, 0, 0);
+        return RT_OK;
+    }
     std::string& err;
     std::map<std::pair<int32_t, int32_t>, uint32_t> memo; // (object, ctx) -> ref
     std::vector<uint8_t> obj_medium;                     // object subtree contains a medium
@@ -470,7 +484,7 @@ struct Flattener {
             if (base + count >= (1ull << 28)) return fail(RT_E_TOO_LARGE, "bvh: more than 2^28 nodes");
             f.nodes.resize(base + count);
             f.wnodes.resize(base + count);
-            build_bvh(items, 0, items.size(), f.nodes.data() + base, f.wnodes.data() + base, base, 0, 0);
+            if (int rcb = build_nodes(items, base)) return rcb;
             ref = make_ref(RT_REF_NODE, (uint32_t)base);
             {
                 bool prim_only = true;
@@ -624,7 +638,7 @@ struct Flattener {
             if (base + count >= (1ull << 28)) return -1;
             f.nodes.resize(base + count);
             f.wnodes.resize(base + count);
-            build_bvh(items, 0, items.size(), f.nodes.data() + base, f.wnodes.data() + base, base, 0, 0);
+            if (build_nodes(items, base)) return -1;
             bvh_roots.push_back((uint32_t)base);
             return (int64_t)base;
         };
@@ -893,8 +907,9 @@ struct Flattener {
 
 } // namespace
 
-int flatten_scene(const rt_scene_desc* desc, FlatScene& out, std::string& err) {
+int flatten_scene(const rt_scene_desc* desc, FlatScene& out, std::string& err, uint64_t device_bvh_min) {
     Flattener fl(desc, out, err);
+    fl.device_bvh_min = device_bvh_min;
     return fl.run();
 }
 

@@ -13,6 +13,8 @@ struct Box { // aabb.rs:10-14 as xmin xmax ymin ymax zmin zmax
     double b[6];
 };
 
+struct BuildItem { Box box; uint32_t ref; uint32_t medium; }; // one object of a BVH under construction: bounding_box(), reference, holds-a-medium flag
+
 struct FlatScene {
     std::vector<DNode> nodes;
     std::vector<WNode> wnodes;
@@ -51,8 +53,12 @@ struct FlatScene {
     Box world_bounds;
 };
 
-// Returns RT_OK or a negative RT_E_* code with `err` set.
-int flatten_scene(const rt_scene_desc* desc, FlatScene& out, std::string& err);
+// BvhNode::from_objects on the current HIP device (bvh_build.hip): same nodes as the host recursion, byte for byte.
+int build_bvh_device(const BuildItem* items, uint64_t n, uint64_t base, DNode* nodes, WNode* wnodes, std::string& err);
+
+// Returns RT_OK or a negative RT_E_* code with `err` set.  device_bvh_min > 0: BVHs over at least that many objects
+// (none of them holding a constant medium) are built on the current HIP device.
+int flatten_scene(const rt_scene_desc* desc, FlatScene& out, std::string& err, uint64_t device_bvh_min = 0);
 
 // Camera::initialize (camera.rs:161-205).
 int camera_initialize(const rt_camera* cam, rt_camera_derived* out, std::string& err);

@@ -527,6 +527,7 @@ struct Tuning {
     bool shade_textures = false; // MI355RT_SHADE_TEXTURES=1: always the full shading kernel
     bool reorder = true;         // MI355RT_REORDER=0: no binning pass in front of large closest-hit batches
     bool debug = false;          // MI355RT_DEBUG: diagnostics on stderr
+    uint64_t device_bvh_min = 1ull << 15; // MI355RT_DEVICE_BVH_MIN: BVHs over at least this many objects are built on the device (0 = never)
     int fast_blocks_per_cu = 0;  // MI355RT_FAST_BLOCKS_PER_CU: cap on the primitive-BVH kernel's workgroups per CU (occupancy experiments)
     uint64_t reorder_min = 1ull << 18; // smallest batch that is binned
     uint64_t tail_paths = 1ull << 16;
@@ -655,6 +656,7 @@ Tuning read_tuning() {
     t.reorder = env_int("MI355RT_REORDER", 1) != 0;
     t.debug = getenv("MI355RT_DEBUG") != nullptr;
     t.fast_blocks_per_cu = env_int("MI355RT_FAST_BLOCKS_PER_CU", 0);
+    t.device_bvh_min = (uint64_t)std::max(0, env_int("MI355RT_DEVICE_BVH_MIN", (int)t.device_bvh_min));
     t.reorder_min = (uint64_t)std::max(1, env_int("MI355RT_REORDER_MIN", (int)t.reorder_min));
     t.tail_paths = (uint64_t)std::max(0, env_int("MI355RT_TAIL_PATHS", TAIL_PATHS));
     // Paths per render batch.  17 GB of path records and queues when a frame is that large (the workspace is sized
@@ -1039,14 +1041,17 @@ int rt_scene_create(const rt_scene_desc* desc, uint32_t flags, rt_scene** out) {
     rt_scene* s = new rt_scene();
     s->tune = read_tuning();
     std::string err;
-    int rc = flatten_scene(desc, s->flat, err);
+    if (!(flags & RT_SCENE_HOST_ONLY)) {
+        hipError_t e = hipGetDevice(&s->device);
+        if (e != hipSuccess) { delete s; return set_err(RT_E_HIP, std::string("no HIP device: ") + hipGetErrorString(e)); }
+    }
+    // large BVHs are built on the device (bvh_build.hip), in the same split order as the host recursion
+    int rc = flatten_scene(desc, s->flat, err, (flags & RT_SCENE_HOST_ONLY) ? 0 : s->tune.device_bvh_min);
     if (rc) { delete s; return set_err(rc, err); }
     if (flags & RT_SCENE_HOST_ONLY) {
         s->host_only = true;
         fill_host_dscene(s);
     } else {
-        hipError_t e = hipGetDevice(&s->device);
-        if (e != hipSuccess) { delete s; return set_err(RT_E_HIP, std::string("no HIP device: ") + hipGetErrorString(e)); }
         rc = upload_scene(s);
         if (rc) { rt_scene_destroy(s); return rc; }
     }
