@@ -299,8 +299,12 @@ def test_reference_side_binding_in_integration_md_covers_the_header():
     """The Rust `extern "C"` block a maintainer of the reference would add (it cannot be compiled here: no Rust
     toolchain) must name every function of the header, and its #[repr(C)] structs must list the fields of the
     ctypes structs in the same order."""
-    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     header = open(os.path.join(ROOT, "include", "mi355rt.h")).read()
+    for source in ("INTEGRATION.md", os.path.join("rust", "mi355rt-sys", "src", "lib.rs")):
+        _check_rust_binding(open(os.path.join(ROOT, source)).read(), header)
+
+
+def _check_rust_binding(text, header):
     declared = set(re.findall(r"^(?:int|void|double|const char\*)\s+(rt_[a-z0-9_]+)\s*\(", header, re.M))
     rust_fns = set(re.findall(r"pub fn (rt_[a-z0-9_]+)\s*\(", text))
     assert rust_fns == declared, rust_fns ^ declared
