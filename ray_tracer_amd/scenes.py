@@ -114,9 +114,12 @@ def checkered_spheres() -> SceneTuple:  # main.rs:204-242
     return world, None, _sky_camera(20.0, Point3(13.0, 2.0, 3.0), Point3(0.0, 0.0, 0.0))
 
 
-def earth() -> SceneTuple:  # main.rs:244-268 (procedural image instead of earthmap.jpg)
+def earth(image_file: str | None = None) -> SceneTuple:  # main.rs:244-268
+    """`image_file` is looked up the way main.rs:245 looks up "earthmap.jpg" (RtwImage.load); the reference does
+    not ship that file, so without a name the globe carries a procedural image of the same role."""
     world = HittableList()
-    world.add(Sphere(Point3(0.0, 0.0, 0.0), 2.0, Lambertian.from_texture(ImageTexture(procedural_image()))))
+    tex = ImageTexture(image_file) if image_file is not None else ImageTexture(procedural_image())
+    world.add(Sphere(Point3(0.0, 0.0, 0.0), 2.0, Lambertian.from_texture(tex)))
     return world, None, _sky_camera(20.0, Point3(0.0, 0.0, 12.0), Point3(0.0, 0.0, 0.0))
 
 

@@ -118,6 +118,23 @@ def test_texture_scenes():
         check(c, a, b)
 
 
+def test_earth_from_an_image_file(tmp_path, monkeypatch):
+    """texture.rs:81-108 over a decoded file: found through $RTW_IMAGES, shaded on the device as in the oracle;
+    a name that is not found shades cyan (texture.rs:92) on both sides."""
+    from PIL import Image
+    yy, xx = np.mgrid[0:64, 0:128]
+    px = np.stack([(xx * 2) % 256, (yy * 4) % 256, (xx + yy) % 256], axis=2).astype(np.uint8)
+    Image.fromarray(px, "RGB").save(tmp_path / "map.png")
+    monkeypatch.setenv("RTW_IMAGES", str(tmp_path))
+    cam, c, a, b, stats, ctr, gpu = render_both(scenes.earth, 64, 9, 50, seed=6, image_file="map.png")
+    check(c, a, b)
+    cam, c, a2, b2, stats, ctr, gpu = render_both(scenes.earth, 64, 9, 50, seed=6, image_file="absent.png")
+    check(c, a2, b2)
+    assert not np.array_equal(a, a2)
+    centre = scaled(c, a2)[a2.shape[0] // 2, a2.shape[1] // 2]
+    assert centre[0] < 0.35 * centre[1] and abs(centre[1] - centre[2]) < 0.35 * centre[1]   # cyan globe: little red
+
+
 def test_mesh_and_spheres_frame_and_its_partition():
     """The multi-GPU frame (sphere BVH + triangle-mesh BVH in one list, metal mesh): parity with the oracle, and
     the per-rank (tile, stratum-range) units of an 8-way partition add up to the unsplit frame."""
