@@ -336,8 +336,10 @@ __global__ __launch_bounds__(BLOCK, 3) void extend_kernel(DScene S, PathState ps
 
 constexpr int SHADE_ROUNDS = 16; // wave-loads of paths whose survivors share one queue reservation
 constexpr unsigned long long SHADE_GROUP = 4ull; // consecutive wave-loads a wave shades before it moves on by a stride of all waves
-template <bool TEXTURES>
-__global__ __launch_bounds__(BLOCK) void shade_kernel(DScene S, CamD cam, PathState ps, int qsel, unsigned long long seed, BatchGeom bg, int last_bounce) {
+// (two workgroups per CU: without the bound the textured variant needs 263 registers, seven over the limit for a
+// second wave per SIMD, which it is worth a few spilled values to keep)
+template <bool TEXTURES, bool RR>
+__global__ __launch_bounds__(BLOCK, 2) void shade_kernel(DScene S, CamD cam, PathState ps, int qsel, unsigned long long seed, BatchGeom bg, int last_bounce) {
     const unsigned long long n = ps.counters[C_LIVE_IN];
     const uint32_t* qin = ps.queue[qsel];
     uint32_t* qout = ps.queue[qsel ^ 1];
@@ -398,7 +400,7 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(DScene S, CamD cam, PathSt
                     Rng g{seed, 0u, (uint32_t)(j * cam.image_width + i), (uint32_t)(bg.sample0 + (int32_t)s_local), rec->rng_index};
                     D3 ray_dir = d3(wr.dx, wr.dy, wr.dz);
                     D3 nd;
-                    alive = shade_hit<TEXTURES>(S, h, ray_dir, g, beta, L, nd, cam.russian_roulette != 0);
+                    alive = shade_hit<TEXTURES, RR>(S, h, ray_dir, g, beta, L, nd);
                     RT_PHASE(2);
                     if (alive) {
                         if (last_bounce) { // the next ray_color call has depth 0 and returns black (camera.rs:252-254)
@@ -445,7 +447,7 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(DScene S, CamD cam, PathSt
 // nearly empty.  Here a lane keeps its path and alternates traversal and shading until the path ends: the batch
 // then takes as long as its slowest path, not the sum over bounces of each bounce's slowest wave.  Same device
 // functions in the same order as extend_kernel + shade_kernel, so the same bits.
-template <bool MEDIA, bool TEXTURES>
+template <bool MEDIA, bool TEXTURES, bool RR>
 __global__ __launch_bounds__(BLOCK) void tail_kernel(DScene S, CamD cam, PathState ps, int qsel, unsigned long long seed, BatchGeom bg,
                                                      int first_bounce, int max_depth) {
     __shared__ uint32_t s_stack[STACK_MAX * BLOCK];
@@ -483,7 +485,7 @@ __global__ __launch_bounds__(BLOCK) void tail_kernel(DScene S, CamD cam, PathSta
             finalize(S, r, time, b, h, TEXTURES && S.uses_uv != 0u);
             D3 ray_dir = d3(r.dx, r.dy, r.dz);
             D3 nd;
-            if (!shade_hit<TEXTURES>(S, h, ray_dir, g, beta, L, nd, cam.russian_roulette != 0)) break;
+            if (!shade_hit<TEXTURES, RR>(S, h, ray_dir, g, beta, L, nd)) break;
             if (bounce == max_depth - 1) { // the next ray_color call has depth 0 and returns black (camera.rs:252-254)
                 L = L + beta * d3(0.0, 0.0, 0.0);
                 break;
@@ -679,14 +681,15 @@ int pick_grid(rt_scene* s) {
     if (s->flat.has_medium) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, extend_kernel<true>, BLOCK, 0));
     else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, extend_kernel<false>, BLOCK, 0));
     int per_cu3 = 0;
-    if (s->flat.has_textures) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu3, shade_kernel<true>, BLOCK, 0));
-    else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu3, shade_kernel<false>, BLOCK, 0));
+    // (grids are sized for the variants without the roulette rule; a render with the rule runs on the same grid)
+    if (s->flat.has_textures) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu3, shade_kernel<true, false>, BLOCK, 0));
+    else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu3, shade_kernel<false, false>, BLOCK, 0));
     s->grid_blocks = prop.multiProcessorCount * std::max(1, per_cu);      // batched closest hit (general kernel)
     s->extend_blocks = prop.multiProcessorCount * std::max(1, per_cu2);   // each kernel fills the chip at its own occupancy
     s->shade_blocks = prop.multiProcessorCount * std::max(1, per_cu3);
     int per_cu4 = 0;
-    if (s->flat.has_medium) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu4, tail_kernel<true, true>, BLOCK, 0));
-    else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu4, tail_kernel<false, true>, BLOCK, 0));
+    if (s->flat.has_medium) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu4, tail_kernel<true, true, false>, BLOCK, 0));
+    else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu4, tail_kernel<false, true, false>, BLOCK, 0));
     s->tail_blocks = prop.multiProcessorCount * std::max(1, per_cu4);
     if (s->flat.fast_root != RT_REF_NONE) {
         s->fast_lds = 0;
@@ -958,6 +961,7 @@ int render_impl(rt_scene* s, const rt_camera* cam, uint64_t seed, const rt_work*
             // MI355RT_FAST_EXTEND=0 keeps the general traversal for BVH-only worlds (A/B measurements)
             const bool fast_extend = s->flat.fast_root != RT_REF_NONE && s->tune.fast_extend;
             const bool has_tex = s->flat.has_textures || s->tune.shade_textures; // the switch forces the full shading code (A/B tests)
+            const bool rr = cam->russian_roulette != 0;
             const uint64_t tail_paths = s->tune.tail_paths;
             const int k_refill = s->tune.refill, k_vote = s->tune.vote, k_chunk = s->tune.chunk, k_pop = s->tune.pop_trips;
             bool live_exact = true; // `live` is the device's count (it is refreshed only now and then)
@@ -965,8 +969,10 @@ int render_impl(rt_scene* s, const rt_camera* cam, uint64_t seed, const rt_work*
                 if (live_exact && bounce > 0 && live <= tail_paths) {
                     // few paths left: they finish in one launch, each lane following its path to the end
                     const int tblocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)s->tail_blocks, (live + BLOCK - 1) / BLOCK));
-                    auto tail = s->flat.has_medium ? (has_tex ? tail_kernel<true, true> : tail_kernel<true, false>)
-                                                   : (has_tex ? tail_kernel<false, true> : tail_kernel<false, false>);
+                    auto tail = rr ? (s->flat.has_medium ? (has_tex ? tail_kernel<true, true, true> : tail_kernel<true, false, true>)
+                                                         : (has_tex ? tail_kernel<false, true, true> : tail_kernel<false, false, true>))
+                                   : (s->flat.has_medium ? (has_tex ? tail_kernel<true, true, false> : tail_kernel<true, false, false>)
+                                                         : (has_tex ? tail_kernel<false, true, false> : tail_kernel<false, false, false>));
                     hipLaunchKernelGGL(tail, dim3(tblocks), dim3(BLOCK), 0, st, s->dev, cd, ps, qsel, (unsigned long long)seed, bg, (int)bounce, (int)cam->max_depth);
                     s->counters.extend_launches += 1;
                     break;
@@ -995,7 +1001,7 @@ int render_impl(rt_scene* s, const rt_camera* cam, uint64_t seed, const rt_work*
                     hipLaunchKernelGGL(s->flat.has_medium ? extend_kernel<true> : extend_kernel<false>, dim3(blocks), dim3(BLOCK), 0, st, s->dev, ps, qsel,
                                        (unsigned long long)seed, bg, cam->image_width, fast_extend ? 1 : 0);
                 }
-                hipLaunchKernelGGL(has_tex ? shade_kernel<true> : shade_kernel<false>, dim3(sblocks), dim3(BLOCK), 0, st, s->dev, cd, ps, qsel, (unsigned long long)seed, bg, bounce == cam->max_depth - 1 ? 1 : 0);
+                hipLaunchKernelGGL(rr ? (has_tex ? shade_kernel<true, true> : shade_kernel<false, true>) : (has_tex ? shade_kernel<true, false> : shade_kernel<false, false>), dim3(sblocks), dim3(BLOCK), 0, st, s->dev, cd, ps, qsel, (unsigned long long)seed, bg, bounce == cam->max_depth - 1 ? 1 : 0);
                 hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, st, s->d_counters);
                 s->counters.extend_launches += 1;
                 qsel ^= 1;

@@ -205,8 +205,10 @@ RT_DEV D3 sample_lobe(const LobeSample& lobe, Rng& g) {
 // ----------------------------------------------------------------- one bounce
 // Returns true when the path continues from the hit point h.p in direction next_d (every scattering material
 // starts the scattered ray at rec.p: material.rs:100, 153, 214, 291); beta/L are updated in place.
-template <bool TEXTURES>
-RT_DEV bool shade_hit(const DScene& S, const HitRec& h, D3 ray_dir, Rng& g, D3& beta, D3& L, D3& next_d, bool russian_roulette) {
+// RR: the termination rule of the reference's history (camera.rs:407-416); a template parameter because the rule's
+// code in the kernel costs the textured shading kernel a wave per SIMD (264 instead of 243 registers).
+template <bool TEXTURES, bool RR>
+RT_DEV bool shade_hit(const DScene& S, const HitRec& h, D3 ray_dir, Rng& g, D3& beta, D3& L, D3& next_d) {
     const DMaterial m = S.materials[h.mat];
     if (m.kind == RT_MAT_DIFFUSE_LIGHT) { // material.rs:237-256: emits on the front face, never scatters
         // The back face emits black, and black still goes through the product: a path whose throughput is NaN
@@ -271,7 +273,7 @@ RT_DEV bool shade_hit(const DScene& S, const HitRec& h, D3 ray_dir, Rng& g, D3& 
     } else {
         scattering_pdf = 1.0 / (4.0 * D_PI);
     }
-    if (russian_roulette) { // the rule of the reference's history (camera.rs:407-416): no re-weighting of survivors
+    if (RR) { // no re-weighting of survivors
         double p = fmax(fmax(attenuation.x, attenuation.y), attenuation.z);
         p = p < 0.1 ? 0.1 : (p > 1.0 ? 1.0 : p);
         if (g.next() >= p) {
