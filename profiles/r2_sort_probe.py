@@ -28,8 +28,13 @@ def spread3(v):
 def main():
     n = int(os.environ.get("PROBE_RAYS", 1 << 24))
     dev = torch.device("cuda", 0)
-    scene = rt.Scene(rt.SceneDesc.from_world(scenes.triangle_soup_scene(1 << 20, seed=2)))
-    o, d, tm = scenes.incoherent_rays(n, [0, 1, 0, 1, 0, 1], seed=3)
+    if os.environ.get("PROBE_SCENE") == "mesh":  # the bench's second figure: closed surface of 1,310,720 triangles
+        scene = rt.Scene(rt.SceneDesc.from_world(rt.Mesh(scenes.icosphere_mesh(subdiv=8), rt.Lambertian(rt.Color(.5, .5, .5)))))
+        b = scene.info().world_bounds
+        o, d, tm = scenes.incoherent_rays(n, [b[k] for k in range(6)], seed=5)
+    else:
+        scene = rt.Scene(rt.SceneDesc.from_world(scenes.triangle_soup_scene(1 << 20, seed=2)))
+        o, d, tm = scenes.incoherent_rays(n, [0, 1, 0, 1, 0, 1], seed=3)
     O = torch.from_numpy(o).to(dev)
     D = torch.from_numpy(d).to(dev)
     stream = torch.cuda.current_stream().cuda_stream
@@ -48,7 +53,10 @@ def main():
             parts = (round(c.ms_last_reorder, 3), round(c.ms_last_traversal, 3))
             if os.environ.get("PROBE_FLAGS"):
                 scene.reset_counters()
-        print(json.dumps({"order": label, "call_ms": round(min(ms[1:]), 3), "reorder_ms, traversal_ms (last)": parts, "Mrays/s": round(n / min(ms[1:]) / 1e3, 1)}), flush=True)
+        t = hits["t"]
+        check = (float(torch.where(torch.isfinite(t), t, torch.zeros_like(t)).sum().item()), int(hits["prim"].to(torch.int64).sum().item()))
+        print(json.dumps({"order": label, "call_ms": round(min(ms[1:]), 3), "reorder_ms, traversal_ms (last)": parts, "Mrays/s": round(n / min(ms[1:]) / 1e3, 1),
+                          "checksum (sum t, sum prim)": check}), flush=True)
         return hits
 
     only = os.environ.get("PROBE_ONLY")  # "none" = just the unsorted launch; "<bits>" = just that Morton order (for counter passes)

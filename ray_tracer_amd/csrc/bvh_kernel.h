@@ -27,6 +27,7 @@
 namespace rt {
 
 constexpr int FAST_BLOCK = 256;
+constexpr int NODES_F32 = 0, NODES_8BIT = 1, NODES_PACKED = 2; // QNode / CQNode / PNode + PTri (device_types.h)
 constexpr int REFILL_THRESHOLD = 40; // refill when fewer lanes than this are still traversing
 constexpr int POP_TRIPS = 2;         // stack entries a lane may take (and discard) per iteration
 constexpr int LEAF_VOTE = 24;        // lanes that must stand on a primitive before the wave runs the intersector
@@ -34,6 +35,7 @@ constexpr int LEAF_VOTE = 24;        // lanes that must stand on a primitive bef
 // with the fabric no longer the bound, running the intersector with fewer lanes costs less than holding lanes back.
 constexpr int PREP_REFILL_THRESHOLD = 56;
 constexpr int PREP_LEAF_VOTE = 16;
+constexpr double POSTPONE_MIN_OVERLAP = 16.0; // FlatScene::fast_leaf_overlap above which primitive tests are postponed
 
 struct RayQueue {              // optional indirection: ray i of the launch is path queue[i]
     const uint32_t* queue;     // nullptr: identity
@@ -55,12 +57,17 @@ struct LaneStack {
 };
 #define RT_STACK_SLOT(k) s_fast_stack[((k) & (LDS_STACK - 1)) * FAST_BLOCK + threadIdx.x]
 #define RT_STACK_RESET(st) do { (st).sp = 0; (st).base = 0; } while (0)
-#define RT_STACK_PUSH(st, ref, near_t)                                                        \
+// Room for k more entries (k <= 3): the oldest LDS entries move to the lane's HBM column.  Checked once per node
+// step, so that the pushes themselves are plain LDS writes.
+#define RT_STACK_RESERVE(st, k)                                                               \
     do {                                                                                      \
-        if ((st).sp - (st).base == LDS_STACK) {                                               \
+        while ((st).sp - (st).base + (k) > LDS_STACK) {                                       \
             (st).spill[(size_t)(st).base * (st).spill_stride] = RT_STACK_SLOT((st).base);     \
             ++(st).base;                                                                      \
         }                                                                                     \
+    } while (0)
+#define RT_STACK_PUSH(st, ref, near_t)                                                        \
+    do {                                                                                      \
         uint2 e_;                                                                             \
         e_.x = (ref); e_.y = __float_as_uint(near_t);                                         \
         RT_STACK_SLOT((st).sp) = e_;                                                          \
@@ -98,13 +105,15 @@ RT_DEV float ubyte_f32(uint32_t w, int byte) { return (float)((w >> (8 * byte)) 
 // (RS = doubles per record; out_t shares that stride, out_prim counts 32-bit words: 2 * RS).
 // PREP: the batch is the array `prep` of prepared records in bin order (reorder.h) instead of `rays`; a record
 // carries the ray's index in the caller's batch, where the result goes.
-template <int PRIM, bool COUNT, bool QUANT, int RS, bool PREP>
+template <int PRIM, bool COUNT, int FMT, int RS, bool PREP>
 __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, uint32_t root, rt_ray_batch rays,
                                                                        unsigned long long n_in, RayQueue rq, uint32_t opt, double tmin_default,
                                                                        float scene_extent, double* out_t, uint32_t* out_prim,
                                                                        unsigned long long* work_counter,
                                                                        unsigned long long* stat_counters, uint2* spill, int refill_threshold,
-                                                                       int leaf_vote, int chunk_in, int pop_trips, const PRay* prep) {
+                                                                       int leaf_vote, int chunk_in, int postpone_leaves, const PRay* prep) {
+    constexpr bool QUANT = FMT != NODES_F32, PACKED = FMT == NODES_PACKED;
+    static_assert(!PACKED || PRIM == RT_REF_TRI, "the packed tree holds triangles only");
     constexpr unsigned long long OUT_T_STRIDE = RS, OUT_PRIM_STRIDE = RS == 1 ? 1 : 2 * RS;
     __shared__ uint2 s_fast_stack[LDS_STACK * FAST_BLOCK];
     LaneStack st;
@@ -121,7 +130,7 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, 
         const unsigned long long per = n / ((unsigned long long)gridDim.x * FAST_WAVES * 8ull);
         chunk = per < 16ull ? 16 : (per > 128ull ? 128 : (int)per);
     }
-    const char* const qbase = QUANT ? reinterpret_cast<const char*>(S.cqnodes) : reinterpret_cast<const char*>(S.qnodes);
+    const char* const qbase = PACKED ? reinterpret_cast<const char*>(S.pnodes) : (QUANT ? reinterpret_cast<const char*>(S.cqnodes) : reinterpret_cast<const char*>(S.qnodes));
 
     bool active = false;
     bool pop = false;  // the lane has to take its next node or primitive from the stack
@@ -145,7 +154,7 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, 
     Ray32 q;
     float tmin32 = 0.0f, best32 = 0.0f;
     double time = 0.0, tmin = 0.0, best_t = 0.0;
-    uint32_t best_ref = RT_REF_NONE, cur = 0;
+    uint32_t best_ref = RT_REF_NONE, cur = 0, pend = RT_REF_NONE;
     unsigned long long ray_slot = 0;
     uint32_t nn = 0, np = 0;
     // wave-level occupancy diagnostics (COUNT builds only): how many lanes take part in each phase
@@ -185,6 +194,7 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, 
                             time = p.time; tmin = p.tmin; best_t = p.tmax;
                             tmin32 = p.tmin32; best32 = p.tmax32;
                             best_ref = RT_REF_NONE;
+                            pend = RT_REF_NONE;
                             ray_slot = p.idx;
                             cur = root;
                             RT_STACK_RESET(st);
@@ -205,6 +215,7 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, 
                         tmin32 = f32_round_down(tmin);
                         best32 = f32_round_up(best_t);
                         best_ref = RT_REF_NONE;
+                        pend = RT_REF_NONE;
                         ray_slot = i;
                         cur = root;
                         RT_STACK_RESET(st);
@@ -229,15 +240,26 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, 
             const bool at_node = active && !pop && (cur >> 28) == REF_QNODE;
             if (COUNT) { ++d_iters; d_run_lanes += __popcll(RT_BALLOT(active)); d_node_lanes += __popcll(RT_BALLOT(at_node)); }
             if (at_node) {
-                uint4 ch;
+                uint4 ch = make_uint4(0u, 0u, 0u, 0u);
+                uint32_t n_inner = 0u, n_all = 0u, inner_base = 0u, leaf_base = 0u; // packed nodes: where the children are
                 float nx[4], fx[4], ny[4], fy[4], nz[4], fz[4]; // entry / exit plane per axis and child
                 float ax, ay, az, bnx, bfx, bny, bfy, bnz, bfz; // t(plane) = plane * a + b
                 if (QUANT) {
-                    const uint4* row = reinterpret_cast<const uint4*>(qbase + (size_t)(cur & 0x0FFFFFFFu) * sizeof(CQNode));
-                    const uint4 h0 = row[0]; // origin x y z | exp x, exp y, exp z
-                    ch = row[1];
-                    const uint4 qa = row[2]; // qlo x | qlo y | qlo z | qhi x   (one byte per child)
-                    const uint4 qb = row[3]; // qhi y | qhi z
+                    uint4 h0, qa, qb;
+                    if (PACKED) {
+                        const uint4* row = reinterpret_cast<const uint4*>(qbase + (size_t)(cur & 0x0FFFFFFFu) * sizeof(PNode));
+                        h0 = row[0];                 // origin x y z | exp x, exp y, exp z, child counts
+                        qa = row[1];                 // qlo x | qlo y | qlo z | qhi x   (one byte per child)
+                        qb = row[2];                 // qhi y | qhi z | first inner child | first triangle - inner children
+                        n_inner = (h0.w >> 24) & 15u; n_all = h0.w >> 28;
+                        inner_base = qb.z; leaf_base = qb.w;
+                    } else {
+                        const uint4* row = reinterpret_cast<const uint4*>(qbase + (size_t)(cur & 0x0FFFFFFFu) * sizeof(CQNode));
+                        h0 = row[0];                 // origin x y z | exp x, exp y, exp z
+                        ch = row[1];
+                        qa = row[2];                 // qlo x | qlo y | qlo z | qhi x   (one byte per child)
+                        qb = row[3];                 // qhi y | qhi z
+                    }
                     // t(plane) = (origin + g * step - o) / d = g * (step * inv) + (origin * inv + c): with
                     // |origin + g * step| <= M the rounding errors of this form stay below the margin E
                     // (at most 7 * 2^-24 * |inv| * (M + |o|)), see Ray32
@@ -275,59 +297,114 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, 
                     ax = q.inv[0]; ay = q.inv[1]; az = q.inv[2];
                     bnx = q.cn[0]; bfx = q.cf[0]; bny = q.cn[1]; bfy = q.cf[1]; bnz = q.cn[2]; bfz = q.cf[2];
                 }
+                if (PACKED) {
+                    // The child in slot j is inner_base + j (j < n_inner) or leaf_base + j, so only the slot number has
+                    // to travel through the sort: it rides in the two lowest bits of the entry distance (cleared first:
+                    // the distance is >= 0 on this path, so that rounds it down and it stays a lower bound), and as
+                    // unsigned integers such keys order like the distances.  An exchange is a min and a max.
+                    uint32_t k[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float tn = fmaxf(fmaxf(__builtin_fmaf(nx[j], ax, bnx), __builtin_fmaf(ny[j], ay, bny)), fmaxf(__builtin_fmaf(nz[j], az, bnz), tmin32));
+                        const float tf = fminf(fminf(__builtin_fmaf(fx[j], ax, bfx), __builtin_fmaf(fy[j], ay, bfy)), fminf(__builtin_fmaf(fz[j], az, bfz), best32));
+                        const bool hit = (tn <= tf) && ((uint32_t)j < n_all);
+                        k[j] = hit ? ((__float_as_uint(tn) & ~3u) | (uint32_t)j) : 0xFFFFFFFFu;
+                        if (COUNT) nn += (uint32_t)j < n_all ? 1u : 0u;
+                    }
+#define RT_USORT2(a, b) do { const uint32_t lo_ = (a) < (b) ? (a) : (b), hi_ = (a) < (b) ? (b) : (a); (a) = lo_; (b) = hi_; } while (0)
+                    RT_USORT2(k[0], k[1]);
+                    RT_USORT2(k[2], k[3]);
+                    RT_USORT2(k[0], k[2]);
+                    RT_USORT2(k[1], k[3]);
+                    RT_USORT2(k[1], k[2]);
+#undef RT_USORT2
+#define RT_SLOT_REF(key_) ((((key_) & 3u) < n_inner ? inner_base : leaf_base) + ((key_) & 3u))
+                    if (k[0] != 0xFFFFFFFFu) {
+                        const bool h1 = k[1] != 0xFFFFFFFFu, h2 = k[2] != 0xFFFFFFFFu, h3 = k[3] != 0xFFFFFFFFu;
+                        RT_STACK_RESERVE(st, (h1 ? 1 : 0) + (h2 ? 1 : 0) + (h3 ? 1 : 0));
+                        if (h3) RT_STACK_PUSH(st, RT_SLOT_REF(k[3]), __uint_as_float(k[3]));
+                        if (h2) RT_STACK_PUSH(st, RT_SLOT_REF(k[2]), __uint_as_float(k[2]));
+                        if (h1) RT_STACK_PUSH(st, RT_SLOT_REF(k[1]), __uint_as_float(k[1]));
+                        cur = RT_SLOT_REF(k[0]);
+                    } else {
+                        pop = true;
+                    }
+#undef RT_SLOT_REF
+                } else {
                 uint32_t rf[4] = {ch.x, ch.y, ch.z, ch.w};
                 float key[4];
-                int nh = 0;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float tn = fmaxf(fmaxf(__builtin_fmaf(nx[j], ax, bnx), __builtin_fmaf(ny[j], ay, bny)), fmaxf(__builtin_fmaf(nz[j], az, bnz), tmin32));
                     const float tf = fminf(fminf(__builtin_fmaf(fx[j], ax, bfx), __builtin_fmaf(fy[j], ay, bfy)), fminf(__builtin_fmaf(fz[j], az, bfz), best32));
                     const bool hit = (tn <= tf) && (rf[j] != RT_REF_NONE);
                     key[j] = hit ? tn : __builtin_inff();
-                    nh += hit ? 1 : 0;
                     if (COUNT) nn += rf[j] != RT_REF_NONE ? 1u : 0u;
                 }
-                if (nh > 0) {
-                    // ascending by entry distance; misses (+inf) sink to the end
-                    sort2(key[0], rf[0], key[1], rf[1]);
-                    sort2(key[2], rf[2], key[3], rf[3]);
-                    sort2(key[0], rf[0], key[2], rf[2]);
-                    sort2(key[1], rf[1], key[3], rf[3]);
-                    sort2(key[1], rf[1], key[2], rf[2]);
-                    if (nh > 3) RT_STACK_PUSH(st, rf[3], key[3]);
-                    if (nh > 2) RT_STACK_PUSH(st, rf[2], key[2]);
-                    if (nh > 1) RT_STACK_PUSH(st, rf[1], key[1]);
+                // ascending by entry distance; misses (+inf) sink to the end.  (Deferring the other children without
+                // sorting them completely saves ten instructions per step and costs 6 % more node visits.)
+                sort2(key[0], rf[0], key[1], rf[1]);
+                sort2(key[2], rf[2], key[3], rf[3]);
+                sort2(key[0], rf[0], key[2], rf[2]);
+                sort2(key[1], rf[1], key[3], rf[3]);
+                sort2(key[1], rf[1], key[2], rf[2]);
+                if (key[0] < __builtin_inff()) {
+                    const bool h1 = key[1] < __builtin_inff(), h2 = key[2] < __builtin_inff(), h3 = key[3] < __builtin_inff();
+                    RT_STACK_RESERVE(st, (h1 ? 1 : 0) + (h2 ? 1 : 0) + (h3 ? 1 : 0));
+                    if (h3) RT_STACK_PUSH(st, rf[3], key[3]);
+                    if (h2) RT_STACK_PUSH(st, rf[2], key[2]);
+                    if (h1) RT_STACK_PUSH(st, rf[1], key[1]);
                     cur = rf[0];
                 } else {
                     pop = true;
                 }
+                }
             }
             RT_TICK(c_node);
             {
-                const bool at_leaf = active && !pop && (cur >> 28) != REF_QNODE;
-                const unsigned long long leaf_mask = RT_BALLOT(at_leaf);
-                const unsigned long long run_mask = RT_BALLOT(active);
-                const bool quorum = __popcll(leaf_mask) >= leaf_vote || leaf_mask == run_mask;
-                if (COUNT && quorum && leaf_mask) { ++d_tri_phases; d_tri_lanes += __popcll(leaf_mask); }
-                if (at_leaf && quorum) {
-                    const uint32_t kind = cur >> 28, idx = cur & 0x0FFFFFFFu;
-                    if (PRIM == RT_REF_TRI || (PRIM == 0 && kind == RT_REF_TRI)) {
+                // A lane that reaches a primitive notes it as pending.  The f64 intersector runs for all pending
+                // primitives of the wave once leaf_vote of them have come together, or when no lane can go on without
+                // it.  Until then the lane waits -- or, with postpone_leaves, goes on with its stack and only waits
+                // when it reaches a second primitive or runs out of stack.  Going on pays where most primitives
+                // reached are missed (a soup of overlapping triangles: -3 %) and costs where the first one reached is
+                // usually the hit that would have cut the rest of the stack (a closed surface: +3 %); the host decides
+                // from the tree (FlatScene::fast_leaf_overlap).
+                bool blocked = false;
+                if (active && !pop && (cur >> 28) != REF_QNODE) {
+                    if (pend != RT_REF_NONE) blocked = true;
+                    else { pend = cur; if (postpone_leaves) pop = true; else blocked = true; }
+                }
+                const bool has_pend = active && pend != RT_REF_NONE;
+                const unsigned long long pend_mask = RT_BALLOT(has_pend);
+                const bool can_go = active && !blocked && (!pop || st.sp > 0);
+                const bool quorum = __popcll(pend_mask) >= leaf_vote || RT_BALLOT(can_go) == 0ull;
+                if (COUNT && quorum && pend_mask) { ++d_tri_phases; d_tri_lanes += __popcll(pend_mask); }
+                if (has_pend && quorum) {
+                    const uint32_t kind = pend >> 28, idx = pend & 0x0FFFFFFFu;
+                    if (PACKED) {
+                        const PTri* tp = S.ptris + idx;
+                        if (COUNT) ++np;
+                        const uint32_t orig = tp->orig; // rides in the request that brings v2.z
+                        double t, u, v;
+                        if (tri_test(d3p(tp->v0), d3p(tp->v1), d3p(tp->v2), r, tmin, best_t, t, u, v)) { best_t = t; best_ref = make_ref(RT_REF_TRI, orig); best32 = f32_round_up(t); }
+                    } else if (PRIM == RT_REF_TRI || (PRIM == 0 && kind == RT_REF_TRI)) {
                         const DTri* tp = S.tris + idx;
                         if (COUNT) ++np;
                         double t, u, v;
-                        if (tri_test(d3p(tp->v0), d3p(tp->v1), d3p(tp->v2), r, tmin, best_t, t, u, v)) { best_t = t; best_ref = cur; best32 = f32_round_up(t); }
+                        if (tri_test(d3p(tp->v0), d3p(tp->v1), d3p(tp->v2), r, tmin, best_t, t, u, v)) { best_t = t; best_ref = pend; best32 = f32_round_up(t); }
                     } else if (PRIM == RT_REF_SPHERE || (PRIM == 0 && kind == RT_REF_SPHERE)) {
                         const DSphere* sph = S.spheres + idx;
                         if (COUNT) ++np;
                         double t;
-                        if (sphere_test(*sph, r, time, tmin, best_t, t)) { best_t = t; best_ref = cur; best32 = f32_round_up(t); }
+                        if (sphere_test(*sph, r, time, tmin, best_t, t)) { best_t = t; best_ref = pend; best32 = f32_round_up(t); }
                     } else { // RT_REF_QUAD
                         const DQuad* qd = S.quads + idx;
                         if (COUNT) ++np;
                         double t, al, be;
-                        if (quad_test(*qd, r, tmin, best_t, t, al, be)) { best_t = t; best_ref = cur; best32 = f32_round_up(t); }
+                        if (quad_test(*qd, r, tmin, best_t, t, al, be)) { best_t = t; best_ref = pend; best32 = f32_round_up(t); }
                     }
-                    pop = true;
+                    pend = RT_REF_NONE;
+                    if (blocked) { if (postpone_leaves) pend = cur; pop = true; }
                 }
             }
             RT_TICK(c_leaf);
@@ -336,8 +413,10 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, 
                 // At most pop_trips entries are taken per iteration.  After a hit most of a lane's stack is
                 // stale (farther than the hit); discarding it all at once would keep the whole wave in this
                 // loop with one or two lanes working, so the rest is left for the following iterations.
-                for (int trip = 0; trip < pop_trips; ++trip) {
+#pragma unroll
+                for (int trip = 0; trip < POP_TRIPS; ++trip) {
                     if (st.sp == 0) {
+                        if (pend != RT_REF_NONE) break; // the ray's last primitive is still to be tested
                         out_t[ray_slot * OUT_T_STRIDE] = best_ref == RT_REF_NONE ? D_INF : best_t;
                         out_prim[ray_slot * OUT_PRIM_STRIDE] = best_ref;
                         active = false;

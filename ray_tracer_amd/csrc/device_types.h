@@ -95,6 +95,32 @@ struct alignas(64) CQNode {
     uint32_t _pad[2];
 };
 
+// The 4-wide tree of a triangle mesh once more, in 48 bytes per node (three 16-byte requests instead of four: the
+// primitive-BVH kernel is bound by the number of divergent requests its lanes put to the vector L1).  The children
+// of a node lie next to each other, so two base indices address them: inner children first, in slots
+// 0 .. n_inner-1, at pnodes[node_base + slot]; then the triangles, at ptris[leaf_base + slot - n_inner].  Boxes as
+// in CQNode.  The array is dense (the CQNode array is indexed like the binary tree and half empty).
+struct alignas(16) PNode {
+    float origin[3];
+    uint8_t exp[3];
+    uint8_t counts;            // low nibble: inner children, high nibble: all children
+    uint8_t qlo[3][4];         // [axis][slot]
+    uint8_t qhi[3][4];
+    uint32_t node_base;        // REF_QNODE << 28 | index of the first inner child
+    uint32_t leaf_base;        // (RT_REF_TRI << 28 | index of the first triangle child in ptris) - n_inner
+};
+static_assert(sizeof(PNode) == 48, "three 16-byte requests");
+
+// Triangles in the order the packed tree's leaves name them; `orig` is the index in DScene::tris, which is what a
+// hit reports.  One line per triangle, as DTri.
+struct alignas(128) PTri {
+    double v0[3];
+    double v1[3];
+    double v2[3];
+    uint32_t orig;
+    uint32_t _pad;
+};
+
 struct DList { uint32_t first, count; };
 
 struct alignas(8) DXform {     // hittable.rs:61-65 / 97-102
@@ -135,6 +161,8 @@ struct DScene {
     const WNode* wnodes;
     const QNode* qnodes;
     const CQNode* cqnodes;
+    const PNode* pnodes;       // packed tree of the primitive-BVH kernel (null unless every leaf is a triangle)
+    const PTri* ptris;
     const DSphere* spheres;
     const DQuad* quads;
     const DTri* tris;

@@ -750,6 +750,62 @@ struct Flattener {
         return ratio_n ? ratio_sum / (double)ratio_n : 1.0;
     }
 
+    // Packed copy (PNode / PTri) of the 8-bit tree at fast_root, when every leaf below it is a triangle.
+    void pack_fast_tree() {
+        f.pnodes.clear();
+        f.ptris.clear();
+        if (f.cqnodes.empty() || f.fast_root == RT_REF_NONE || f.fast_partial) return;
+        std::vector<std::pair<uint32_t, uint32_t>> todo; // (index in cqnodes, index in pnodes)
+        auto half_area = [](const Box& b) {
+            const double dx = b.b[1] - b.b[0], dy = b.b[3] - b.b[2], dz = b.b[5] - b.b[4];
+            return dx * dy + dy * dz + dz * dx;
+        };
+        double leaf_area = 0.0;
+        f.pnodes.emplace_back();
+        todo.emplace_back(RT_REF_INDEX(f.fast_root), 0u);
+        while (!todo.empty()) {
+            const uint32_t q = todo.back().first, me = todo.back().second;
+            todo.pop_back();
+            const CQNode& c = f.cqnodes[q];
+            int order[4], n_inner = 0, n_all = 0;
+            for (int j = 0; j < 4; ++j)
+                if (c.child[j] != RT_REF_NONE && RT_REF_KIND(c.child[j]) == REF_QNODE) order[n_all++] = j;
+            n_inner = n_all;
+            for (int j = 0; j < 4; ++j) {
+                if (c.child[j] == RT_REF_NONE || RT_REF_KIND(c.child[j]) == REF_QNODE) continue;
+                if (RT_REF_KIND(c.child[j]) != RT_REF_TRI) { f.pnodes.clear(); f.ptris.clear(); return; }
+                order[n_all++] = j;
+            }
+            PNode n{};
+            for (int a = 0; a < 3; ++a) { n.origin[a] = c.origin[a]; n.exp[a] = c.exp[a]; }
+            n.counts = (uint8_t)(n_inner | (n_all << 4));
+            for (int k = 0; k < 4; ++k)
+                for (int a = 0; a < 3; ++a) {
+                    n.qlo[a][k] = k < n_all ? c.qlo[a][order[k]] : 255;
+                    n.qhi[a][k] = k < n_all ? c.qhi[a][order[k]] : 0;
+                }
+            const uint32_t node_base = (uint32_t)f.pnodes.size(), leaf_base = (uint32_t)f.ptris.size();
+            if ((uint64_t)node_base + 4u >= (1ull << 28) || (uint64_t)leaf_base + 4u >= (1ull << 28)) { f.pnodes.clear(); f.ptris.clear(); return; }
+            n.node_base = make_ref(REF_QNODE, node_base);
+            n.leaf_base = make_ref(RT_REF_TRI, leaf_base) - (uint32_t)n_inner;
+            for (int k = 0; k < n_inner; ++k) {
+                f.pnodes.emplace_back();
+                todo.emplace_back(RT_REF_INDEX(c.child[order[k]]), node_base + (uint32_t)k);
+            }
+            for (int k = n_inner; k < n_all; ++k) {
+                const uint32_t t = RT_REF_INDEX(c.child[order[k]]);
+                leaf_area += half_area(tri_box(t));
+                PTri pt{};
+                for (int a = 0; a < 3; ++a) { pt.v0[a] = f.tris[t].v0[a]; pt.v1[a] = f.tris[t].v1[a]; pt.v2[a] = f.tris[t].v2[a]; }
+                pt.orig = t;
+                f.ptris.push_back(pt);
+            }
+            f.pnodes[me] = n;
+        }
+        const double ra = half_area(f.world_bounds);
+        f.fast_leaf_overlap = ra > 0.0 ? leaf_area / ra : 0.0;
+    }
+
     // Stack entries the ordered traversal can need below 4-wide node `q`: up to (children - 1) siblings stay deferred
     // while one child is walked, and that child is another 4-wide node or a leaf with a need of its own (a list pushes
     // its continuation, an instance its restore entry, and what is below them goes on top of that).
@@ -890,6 +946,7 @@ struct Flattener {
                 f.lists.push_back(DList{w.first + 1u, w.count - 1u}); // shares the world's items
             }
         }
+        pack_fast_tree();
         need_node.assign(f.nodes.size(), -1);
         f.max_stack = (uint32_t)need(f.world) + 1;
         if (f.max_stack > (uint32_t)STACK_MAX) {

@@ -19,6 +19,8 @@ struct FlatScene {
     std::vector<DNode> nodes;
     std::vector<WNode> wnodes;
     std::vector<QNode> qnodes;        // 4-wide collapse of the BVH at fast_root (empty otherwise)
+    std::vector<PNode> pnodes;        // packed 48-byte copy of the tree at fast_root (node 0 is the root); empty unless all its leaves are triangles
+    std::vector<PTri> ptris;          // its triangles in leaf order
     std::vector<CQNode> cqnodes;      // the same nodes with 8-bit boxes (same indices); empty when the grid would be too coarse
     std::vector<DSphere> spheres;
     std::vector<DQuad> quads;
@@ -46,6 +48,8 @@ struct FlatScene {
                                       // with the first member's closest hit as the interval's upper end (list order: hittable_list.rs:46-57)
     uint32_t world_rest = RT_REF_NONE;
     float q_extent = 0.0f;            // largest |coordinate| in qnodes
+    double fast_leaf_overlap = 0.0;   // packed tree: sum of the leaf boxes' surface areas over the root's, i.e. the number of
+                                      // triangle boxes a random line through the scene's box crosses
     double quant_inflation = 0.0;     // mean surface-area ratio of the 8-bit child boxes to their f32 boxes
     bool has_medium = false;
     bool uses_uv = false;             // an image texture exists: shading needs the spheres' (u,v)

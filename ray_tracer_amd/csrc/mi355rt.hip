@@ -522,9 +522,11 @@ __global__ __launch_bounds__(BLOCK) void accumulate_kernel(PathState ps, BatchGe
 // ============================================================================ host code
 // Measurement switches, read from the environment ONCE, when a scene is created (never per launch).
 struct Tuning {
-    int refill = REFILL_THRESHOLD, vote = LEAF_VOTE, chunk = 0, pop_trips = POP_TRIPS; // primitive-BVH kernel scheduling
+    int refill = REFILL_THRESHOLD, vote = LEAF_VOTE, chunk = 0; // primitive-BVH kernel scheduling
     int prep_refill = PREP_REFILL_THRESHOLD, prep_vote = PREP_LEAF_VOTE;               // the same for reordered batches
     bool quant = true;           // MI355RT_QUANT=0: keep the f32 4-wide nodes
+    int postpone = -1;           // MI355RT_POSTPONE=0/1: overrides the choice made from the tree (postponed primitive tests)
+    bool packed = true;          // MI355RT_PACKED=0: keep the 64-byte 8-bit nodes where the 48-byte packed tree exists
     bool fast_extend = true;     // MI355RT_FAST_EXTEND=0: the renderer keeps the general traversal
     bool shade_textures = false; // MI355RT_SHADE_TEXTURES=1: always the full shading kernel
     bool reorder = true;         // MI355RT_REORDER=0: no binning pass in front of large closest-hit batches
@@ -563,7 +565,8 @@ struct rt_scene {
     int32_t* hit_ctx = nullptr;  // transform context of every hit of the current general closest-hit batch
     uint64_t hit_ctx_cap = 0;
     int fast_prim = 0;           // leaf kind of the primitive BVH when uniform, else 0
-    bool fast_quant = false;     // the primitive-BVH kernel reads the 64-byte nodes with 8-bit boxes
+    int fast_fmt = NODES_F32;    // node records the primitive-BVH kernel reads (bvh_kernel.h)
+    uint32_t fast_entry = RT_REF_NONE; // its root in that format
     float fast_extent = 0.0f; // largest |coordinate| stored in the 4-wide nodes (error bound of the f32 slab test)
     // render workspace
     PathState ps{};
@@ -624,22 +627,21 @@ int upload(rt_scene* s, const std::vector<T>& v, const T** out) {
 
 using FastKernel = void (*)(DScene, uint32_t, rt_ray_batch, unsigned long long, RayQueue, uint32_t, double, float, double*, uint32_t*,
                             unsigned long long*, unsigned long long*, uint2*, int, int, int, int, const PRay*);
-template <bool COUNT, bool QUANT, int RS, bool PREP> FastKernel fast_kernel_for(int prim) {
-    if (prim == (int)RT_REF_TRI) return bvh4_closest_hit_kernel<RT_REF_TRI, COUNT, QUANT, RS, PREP>;
-    if (prim == (int)RT_REF_SPHERE) return bvh4_closest_hit_kernel<RT_REF_SPHERE, COUNT, QUANT, RS, PREP>;
-    return bvh4_closest_hit_kernel<0, COUNT, QUANT, RS, PREP>;
+// fmt: NODES_F32 / NODES_8BIT / NODES_PACKED (bvh_kernel.h); the packed tree exists for triangle meshes only
+template <bool COUNT, int FMT, int RS, bool PREP> FastKernel fast_kernel_for(int prim) {
+    if (prim == (int)RT_REF_TRI) return bvh4_closest_hit_kernel<RT_REF_TRI, COUNT, FMT, RS, PREP>;
+    if (FMT == NODES_PACKED) return nullptr;
+    if (prim == (int)RT_REF_SPHERE) return bvh4_closest_hit_kernel<RT_REF_SPHERE, COUNT, FMT == NODES_PACKED ? NODES_8BIT : FMT, RS, PREP>;
+    return bvh4_closest_hit_kernel<0, COUNT, FMT == NODES_PACKED ? NODES_8BIT : FMT, RS, PREP>;
 }
-FastKernel fast_kernel(int prim, bool count, bool quant) { // structure-of-arrays batches of the C ABI
-    if (quant) return count ? fast_kernel_for<true, true, 1, false>(prim) : fast_kernel_for<false, true, 1, false>(prim);
-    return count ? fast_kernel_for<true, false, 1, false>(prim) : fast_kernel_for<false, false, 1, false>(prim);
+template <int RS, bool PREP> FastKernel fast_kernel_pick(int prim, bool count, int fmt) {
+    if (fmt == NODES_PACKED) return count ? fast_kernel_for<true, NODES_PACKED, RS, PREP>(prim) : fast_kernel_for<false, NODES_PACKED, RS, PREP>(prim);
+    if (fmt == NODES_8BIT) return count ? fast_kernel_for<true, NODES_8BIT, RS, PREP>(prim) : fast_kernel_for<false, NODES_8BIT, RS, PREP>(prim);
+    return count ? fast_kernel_for<true, NODES_F32, RS, PREP>(prim) : fast_kernel_for<false, NODES_F32, RS, PREP>(prim);
 }
-FastKernel fast_kernel_prepared(int prim, bool count, bool quant) { // batches binned and prepared by the reorder pass
-    if (quant) return count ? fast_kernel_for<true, true, 1, true>(prim) : fast_kernel_for<false, true, 1, true>(prim);
-    return count ? fast_kernel_for<true, false, 1, true>(prim) : fast_kernel_for<false, false, 1, true>(prim);
-}
-FastKernel fast_kernel_paths(int prim, bool quant) { // strided views of the renderer's path records
-    return quant ? fast_kernel_for<false, true, (int)PATH_DOUBLES, false>(prim) : fast_kernel_for<false, false, (int)PATH_DOUBLES, false>(prim);
-}
+FastKernel fast_kernel(int prim, bool count, int fmt) { return fast_kernel_pick<1, false>(prim, count, fmt); }          // structure-of-arrays batches of the C ABI
+FastKernel fast_kernel_prepared(int prim, bool count, int fmt) { return fast_kernel_pick<1, true>(prim, count, fmt); }  // batches binned and prepared by the reorder pass
+FastKernel fast_kernel_paths(int prim, int fmt) { return fast_kernel_pick<(int)PATH_DOUBLES, false>(prim, false, fmt); } // strided views of the renderer's path records
 int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
     return e ? atoi(e) : dflt;
@@ -649,7 +651,8 @@ Tuning read_tuning() {
     t.refill = env_int("MI355RT_REFILL", t.refill);
     t.vote = env_int("MI355RT_VOTE", t.vote);
     t.chunk = env_int("MI355RT_CHUNK", t.chunk);
-    t.pop_trips = env_int("MI355RT_POP_TRIPS", t.pop_trips);
+    t.packed = env_int("MI355RT_PACKED", 1) != 0;
+    t.postpone = env_int("MI355RT_POSTPONE", -1);
     t.prep_refill = env_int("MI355RT_PREP_REFILL", t.prep_refill);
     t.prep_vote = env_int("MI355RT_PREP_VOTE", t.prep_vote);
     t.quant = env_int("MI355RT_QUANT", 1) != 0;
@@ -697,9 +700,10 @@ int pick_grid(rt_scene* s) {
         const bool tr = !s->flat.tris.empty(), sp = !s->flat.spheres.empty(), qd = !s->flat.quads.empty();
         s->fast_prim = (tr && !sp && !qd) ? (int)RT_REF_TRI : ((sp && !tr && !qd) ? (int)RT_REF_SPHERE : 0);
         int fast_per_cu = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fast_per_cu, fast_kernel(s->fast_prim, false, s->fast_quant), FAST_BLOCK, 0));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fast_per_cu, fast_kernel(s->fast_prim, false, s->fast_fmt), FAST_BLOCK, 0));
         if (s->tune.debug)
-            fprintf(stderr, "[mi355rt] primitive-BVH kernel: 8-bit nodes=%d (inflation %.3f) blocks/CU=%d\n", (int)s->fast_quant, s->flat.quant_inflation, fast_per_cu);
+            fprintf(stderr, "[mi355rt] primitive-BVH kernel: node format=%d (inflation %.3f, leaf overlap %.2f) blocks/CU=%d\n", s->fast_fmt, s->flat.quant_inflation,
+                    s->flat.fast_leaf_overlap, fast_per_cu);
         if (s->tune.fast_blocks_per_cu > 0) fast_per_cu = std::min(fast_per_cu, s->tune.fast_blocks_per_cu);
         s->fast_grid_blocks = prop.multiProcessorCount * std::max(1, fast_per_cu);
         {
@@ -718,7 +722,7 @@ int pick_grid(rt_scene* s) {
 void fill_host_dscene(rt_scene* s) {
     FlatScene& f = s->flat;
     DScene& d = s->dev;
-    d.nodes = f.nodes.data(); d.wnodes = f.wnodes.data(); d.qnodes = f.qnodes.data(); d.cqnodes = f.cqnodes.data(); d.spheres = f.spheres.data(); d.quads = f.quads.data(); d.tris = f.tris.data();
+    d.nodes = f.nodes.data(); d.wnodes = f.wnodes.data(); d.qnodes = f.qnodes.data(); d.cqnodes = f.cqnodes.data(); d.pnodes = f.pnodes.data(); d.ptris = f.ptris.data(); d.spheres = f.spheres.data(); d.quads = f.quads.data(); d.tris = f.tris.data();
     d.lists = f.lists.data(); d.list_items = f.list_items.data(); d.xforms = f.xforms.data();
     d.media = f.media.data(); d.materials = f.materials.data(); d.textures = f.textures.data(); d.images = f.images.data();
     d.image_bytes = f.image_bytes.data(); d.perlins = f.perlins.data(); d.lights = f.lights.data();
@@ -734,10 +738,18 @@ int upload_scene(rt_scene* s) {
     // the f32 4-wide nodes always go to the device (the general kernel's ordered traversal enters them at every BVH
     // root); the 8-bit copy only when the primitive-BVH kernel will read it
     // (MI355RT_QUANT=0 keeps that kernel on the f32 nodes even when the 8-bit ones were accepted, for A/B measurements)
-    s->fast_quant = !f.cqnodes.empty() && s->tune.quant;
+    // MI355RT_PACKED=0 keeps it on the 64-byte nodes when the packed tree exists
+    s->fast_fmt = (!f.cqnodes.empty() && s->tune.quant) ? ((!f.pnodes.empty() && s->tune.packed) ? NODES_PACKED : NODES_8BIT) : NODES_F32;
+    s->fast_entry = s->fast_fmt == NODES_PACKED ? make_ref(REF_QNODE, 0u) : f.fast_root;
     const std::vector<CQNode> no_cqnodes;
+    const std::vector<PNode> no_pnodes;
+    const std::vector<PTri> no_ptris;
     if ((rc = upload(s, f.qnodes, &d.qnodes))) return rc;
-    if ((rc = upload(s, s->fast_quant ? f.cqnodes : no_cqnodes, &d.cqnodes))) return rc;
+    // (a batch that brings its own tmin array may hold negative ones, which the packed nodes' integer sort keys do not
+    // cover: such a batch is traced on the 64-byte nodes, so both copies go to the device)
+    if ((rc = upload(s, s->fast_fmt != NODES_F32 ? f.cqnodes : no_cqnodes, &d.cqnodes))) return rc;
+    if ((rc = upload(s, s->fast_fmt == NODES_PACKED ? f.pnodes : no_pnodes, &d.pnodes))) return rc;
+    if ((rc = upload(s, s->fast_fmt == NODES_PACKED ? f.ptris : no_ptris, &d.ptris))) return rc;
     if ((rc = upload(s, f.spheres, &d.spheres))) return rc;
     if ((rc = upload(s, f.quads, &d.quads))) return rc;
     if ((rc = upload(s, f.tris, &d.tris))) return rc;
@@ -854,10 +866,16 @@ int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit
             HIP_TRY(hipGetLastError());
         }
         HIP_TRY(hipEventRecord(ev[1], st));
-        hipLaunchKernelGGL(reorder ? fast_kernel_prepared(s->fast_prim, count, s->fast_quant) : fast_kernel(s->fast_prim, count, s->fast_quant),
-                           dim3(fblocks), dim3(FAST_BLOCK), 0, st, s->dev, s->flat.fast_root, *rays, (unsigned long long)n, rq, opt, 0.001,
+        // the packed nodes order children by keys that need entry distances >= 0, i.e. tmin >= 0: certain only for the default tmin
+        const int fmt = (s->fast_fmt == NODES_PACKED && (opt & 2u)) ? NODES_8BIT : s->fast_fmt;
+        const uint32_t entry = fmt == s->fast_fmt ? s->fast_entry : s->flat.fast_root;
+        // lanes go on past a primitive they have reached where a ray crosses many triangle boxes (bvh_kernel.h);
+        // measured: the 2^20-triangle soup (overlap 70) gains 3 %, a closed surface of 1.3 M triangles (overlap 3.9) loses 3 %
+        const int postpone = tn.postpone >= 0 ? tn.postpone : (fmt == NODES_PACKED && reorder && s->flat.fast_leaf_overlap > POSTPONE_MIN_OVERLAP ? 1 : 0);
+        hipLaunchKernelGGL(reorder ? fast_kernel_prepared(s->fast_prim, count, fmt) : fast_kernel(s->fast_prim, count, fmt),
+                           dim3(fblocks), dim3(FAST_BLOCK), 0, st, s->dev, entry, *rays, (unsigned long long)n, rq, opt, 0.001,
                            s->fast_extent, hits->t, hits->prim, s->d_counters + C_WORK_SLOTS, s->d_counters + C_NODES, s->fast_spill,
-                           reorder ? tn.prep_refill : tn.refill, reorder ? tn.prep_vote : tn.vote, tn.chunk, tn.pop_trips, (const PRay*)s->prep);
+                           reorder ? tn.prep_refill : tn.refill, reorder ? tn.prep_vote : tn.vote, tn.chunk, postpone, (const PRay*)s->prep);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev[2], st));
         if (hits->u || hits->v || hits->front_face || hits->mat || hits->nx || hits->ny || hits->nz || hits->px || hits->py || hits->pz)
@@ -885,9 +903,9 @@ int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit
         int fblocks = (int)std::min<uint64_t>((uint64_t)s->fast_grid_blocks, (waves + (FAST_BLOCK / 64) - 1) / (FAST_BLOCK / 64));
         RayQueue rq{nullptr, nullptr};
         const uint32_t opt = (rays->time ? 1u : 0u) | (rays->tmin ? 2u : 0u) | (rays->tmax ? 4u : 0u);
-        hipLaunchKernelGGL(fast_kernel(s->fast_prim, false, s->fast_quant), dim3(fblocks), dim3(FAST_BLOCK), 0, st, s->dev, s->flat.fast_root, *rays,
+        hipLaunchKernelGGL(fast_kernel(s->fast_prim, false, s->fast_fmt), dim3(fblocks), dim3(FAST_BLOCK), 0, st, s->dev, s->fast_entry, *rays,
                            (unsigned long long)n, rq, opt, 0.001, s->fast_extent, hits->t, hits->prim, s->d_counters + C_WORK_SLOTS, s->d_counters + C_NODES,
-                           s->fast_spill, tn.refill, tn.vote, tn.chunk, tn.pop_trips, (const PRay*)nullptr);
+                           s->fast_spill, tn.refill, tn.vote, tn.chunk, 0, (const PRay*)nullptr);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemsetAsync(s->d_counters + C_WORK_SLOTS, 0, WORK_SLOTS * WORK_STRIDE * sizeof(unsigned long long), st));
     }
@@ -963,7 +981,7 @@ int render_impl(rt_scene* s, const rt_camera* cam, uint64_t seed, const rt_work*
             const bool has_tex = s->flat.has_textures || s->tune.shade_textures; // the switch forces the full shading code (A/B tests)
             const bool rr = cam->russian_roulette != 0;
             const uint64_t tail_paths = s->tune.tail_paths;
-            const int k_refill = s->tune.refill, k_vote = s->tune.vote, k_chunk = s->tune.chunk, k_pop = s->tune.pop_trips;
+            const int k_refill = s->tune.refill, k_vote = s->tune.vote, k_chunk = s->tune.chunk;
             bool live_exact = true; // `live` is the device's count (it is refreshed only now and then)
             for (int32_t bounce = 0; bounce < cam->max_depth && live > 0; ++bounce) {
                 if (live_exact && bounce > 0 && live <= tail_paths) {
@@ -992,9 +1010,9 @@ int render_impl(rt_scene* s, const rt_camera* cam, uint64_t seed, const rt_work*
                     double* out_t = reinterpret_cast<double*>(ps.rec) + offsetof(PathRec, hit_t) / sizeof(double);
                     uint32_t* out_prim = reinterpret_cast<uint32_t*>(ps.rec) + offsetof(PathRec, hit_ref) / sizeof(uint32_t);
                     int fblocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)s->fast_grid_blocks, (waves + (FAST_BLOCK / 64) - 1) / (FAST_BLOCK / 64)));
-                    hipLaunchKernelGGL(fast_kernel_paths(s->fast_prim, s->fast_quant), dim3(fblocks), dim3(FAST_BLOCK), 0, st, s->dev, s->flat.fast_root,
+                    hipLaunchKernelGGL(fast_kernel_paths(s->fast_prim, s->fast_fmt), dim3(fblocks), dim3(FAST_BLOCK), 0, st, s->dev, s->fast_entry,
                                        view, (unsigned long long)live, rq, 1u, 0.001, s->fast_extent, out_t, out_prim, s->d_counters + C_WORK_SLOTS,
-                                       s->d_counters + C_NODES, s->fast_spill, k_refill, k_vote, k_chunk, k_pop, (const PRay*)nullptr);
+                                       s->d_counters + C_NODES, s->fast_spill, k_refill, k_vote, k_chunk, 0, (const PRay*)nullptr);
                 }
                 if (!fast_extend || s->flat.fast_partial) { // the whole world, or what follows its first member
                     if (fast_extend) hipLaunchKernelGGL(reset_work_kernel, dim3(1), dim3(1), 0, st, s->d_counters);

@@ -297,6 +297,33 @@ def test_primitive_bvh_kernel_edge_cases():
             compare(desc, oo[:n], dd[:n], min_hits=0, flags=F.RT_HIT_ORDERED)
 
 
+def test_packed_and_64_byte_nodes_agree(monkeypatch):
+    """A triangle mesh is traced on the 48-byte packed nodes (children addressed from two base indices, triangles in
+    leaf order); MI355RT_PACKED=0 keeps the 64-byte nodes.  Same boxes, so the same (t, primitive), also with caller
+    intervals that only bound t from above (the packed kernel's sort keys need tmin >= 0)."""
+    m = rt.Lambertian(rt.Color(.5, .5, .5))
+    desc = rt.SceneDesc.from_world(rt.Mesh(scenes.triangle_soup(20000, seed=41, edge=0.05), m))
+    o, d, tm = scenes.incoherent_rays(40000, [0, 1, 0, 1, 0, 1], seed=42)
+    tmax = np.random.default_rng(7).uniform(0.05, 2.0, len(o))
+    packed = rt.Scene(desc)
+    monkeypatch.setenv("MI355RT_PACKED", "0")
+    plain = rt.Scene(desc)
+    monkeypatch.delenv("MI355RT_PACKED")
+    for kw in ({}, {"tmax": tmax}):
+        a = packed.closest_hit(o, d, flags=F.RT_HIT_ORDERED | F.RT_HIT_COUNTERS, **kw)
+        b = plain.closest_hit(o, d, flags=F.RT_HIT_ORDERED | F.RT_HIT_COUNTERS, **kw)
+        assert np.array_equal(a["t"], b["t"]) and (a["prim"] != -1).sum() > 10000
+        same = a["prim"] == b["prim"]
+        assert same.mean() > 0.9999  # an exact tie between two triangles may go to either
+        for k in ("u", "v", "front_face", "mat"):
+            assert np.array_equal(a[k][same], b[k][same]), k
+    ca, cb = packed.counters(), plain.counters()
+    # (children with equal entry distances may be visited in another order: the counts agree closely, not exactly)
+    assert abs(int(ca.node_visits) - int(cb.node_visits)) <= 0.01 * cb.node_visits and ca.prim_tests > 0
+    compare(desc, o[:5000], d[:5000], min_hits=1000, flags=F.RT_HIT_ORDERED)
+    packed.close(); plain.close()
+
+
 def test_deep_stacks_of_instanced_nested_lists():
     """A BVH over Translate(RotateY(nested lists)) leaves: the ordered traversal keeps deferred siblings, restore
     entries and list continuations on the LDS stack at the same time (up to 23 entries with 4-wide nodes here, 27
