@@ -296,6 +296,15 @@ def _render_figure(rt, F, scenes, np, name, with_cpu):
     fig = {"metric": "camera samples/s", "scene": f"{name} {cam.image_width}x{d.image_height}, {n_strata} samples/pixel, depth {cam.max_depth}",
            "value": paths / wall, "unit": "samples/s", "ms_frame": 1e3 * wall, "device_ms": cnt.ms_last_render,
            "extend_queries": int(cnt.render_rays)}
+    # Bytes of path state the wavefront kernels move per path-bounce (a world.hit query and the shading of its result):
+    # extend reads the 128-byte path record and writes its 16-byte hit block, shade reads the record and writes it back,
+    # and the path's 4-byte queue entry is read by both and written once; per path, raygen writes the record once and
+    # accumulate reads the 24 bytes of radiance.  Scene data (nodes, primitives, materials) is not counted: it is shared
+    # by the paths in flight and mostly served on-die.
+    bounces = max(1, int(cnt.render_rays))
+    per_bounce = (128 + 16) + (128 + 128) + 3 * 4 + (128 + 24) * paths / bounces
+    fig["roofline"] = {"bound": "hbm", "bytes_per_path_bounce": per_bounce, "achieved": per_bounce * bounces / (cnt.ms_last_render * 1e-3) / 1e9,
+                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": per_bounce * bounces / (cnt.ms_last_render * 1e-3) / 1e9 / HBM_PEAK_GBS}
     if with_cpu:
         import oracle_ffi as O
         rows, threads = (200 if name == "book2_final" else 600), min(16, os.cpu_count() or 1)
