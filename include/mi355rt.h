@@ -270,7 +270,10 @@ typedef struct rt_hit_batch {
                                      corner and can so report a hit the reference never tests (see RT_HIT_ORDERED). */
 
 /* Random numbers drawn inside traversal (constant_medium.rs:90) come from the
- * counter-based stream (seed, stream 2, ray index); see rt_rng_uniform. */
+ * counter-based stream (seed, stream 2, ray index); see rt_rng_uniform.
+ * One call in flight per scene: a scene owns one set of work counters, one path workspace and one set of
+ * timing events, so two rt_closest_hit* / rt_render* calls on the same rt_scene must not overlap, whatever
+ * streams they use (different scenes are independent).  The *_device entry points enqueue and return. */
 int rt_closest_hit(rt_scene* scene, const rt_ray_batch* rays, uint64_t n,
                    rt_hit_batch* hits, uint64_t seed, uint32_t flags);          /* host pointers */
 int rt_closest_hit_device(rt_scene* scene, const rt_ray_batch* rays, uint64_t n,

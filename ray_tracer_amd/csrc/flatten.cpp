@@ -357,7 +357,7 @@ struct Flattener {
                         int32_t c = d->children[idx];
                         if (!child_ok(c)) return fail(RT_E_INVALID, "object: a child must have a smaller id than its parent");
                         b = box_union(b, f.object_bounds[c]);
-                        obj_medium[i] |= obj_medium[c];
+                        obj_medium[i] = std::max(obj_medium[i], obj_medium[c]);
                     } else if (o.child_kind == RT_CHILD_SPHERES) b = box_union(b, sphere_box(idx));
                     else if (o.child_kind == RT_CHILD_QUADS) b = box_union(b, quad_box(idx));
                     else b = box_union(b, tri_box(idx));
@@ -396,12 +396,13 @@ struct Flattener {
             case RT_OBJ_CONSTANT_MEDIUM: // constant_medium.rs:106-108
                 if (!child_ok(o.a)) return fail(RT_E_INVALID, "constant_medium: bad boundary");
                 if (!mat_ok(o.mat)) return fail(RT_E_INVALID, "constant_medium: material out of range");
-                if (obj_medium[o.a]) return fail(RT_E_UNSUPPORTED, "constant_medium: a medium inside the boundary of a medium is not supported");
+                if (obj_medium[o.a] >= 2) return fail(RT_E_UNSUPPORTED, "constant_medium: media nested more than two deep are not supported");
                 if (d->materials[o.mat].kind == RT_MAT_ISOTROPIC && texture_uses_uv(d->materials[o.mat].tex))
                     return fail(RT_E_UNSUPPORTED, "constant_medium: the reference never writes u,v for a medium hit (constant_medium.rs:96-101); "
                                                   "a phase function with an image texture would read stale values and is not supported");
                 b = f.object_bounds[o.a];
-                obj_medium[i] = 1;
+                obj_medium[i] = (uint8_t)(1 + obj_medium[o.a]);
+                f.medium_depth = std::max(f.medium_depth, (int)obj_medium[i]);
                 break;
             case RT_OBJ_OBJMODEL: { // obj_loader.rs:38-39,70-71,103-105
                 if (o.a < 0 || o.b < 0 || (uint64_t)o.a + (uint64_t)o.b > d->n_triangles) return fail(RT_E_INVALID, "objmodel: triangle range out of bounds");
@@ -435,7 +436,7 @@ struct Flattener {
                 uint32_t r;
                 int rc = flatten_object(c, ctx, r);
                 if (rc) return rc;
-                it.ref = r; it.box = f.object_bounds[c]; it.medium = obj_medium[c];
+                it.ref = r; it.box = f.object_bounds[c]; it.medium = obj_medium[c] ? 1 : 0;
                 break;
             }
             case RT_CHILD_SPHERES: it.ref = make_ref(RT_REF_SPHERE, (uint32_t)idx); it.box = sphere_box(idx); break;

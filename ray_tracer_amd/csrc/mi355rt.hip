@@ -142,7 +142,7 @@ struct WaveWork {
 };
 
 // MEDIA = false: the scene holds no constant medium; the nested boundary queries and the random draw are compiled out.
-template <bool COUNT, bool ORDERED, bool MEDIA>
+template <bool COUNT, bool ORDERED, int MEDIA>
 __global__ __launch_bounds__(BLOCK) void closest_hit_kernel(DScene S, rt_ray_batch rays, unsigned long long n, rt_hit_batch hits,
                                                             int32_t* hit_ctx, unsigned long long seed, unsigned long long* counters, int rest_only,
                                                             int axis_order) {
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(BLOCK) void raygen_kernel(CamD cam, BatchGeom bg, P
 // traversal are compiled out (fewer registers, one more wave per SIMD).
 // At least 3 waves per SIMD (168 registers): the variant with media sits within a few registers of that limit,
 // and one wave less costs it more than 10 %.
-template <bool MEDIA>
+template <int MEDIA>
 __global__ __launch_bounds__(BLOCK, 3) void extend_kernel(DScene S, PathState ps, int qsel, unsigned long long seed, BatchGeom bg, int32_t image_width,
                                                           int rest_only) {
     __shared__ uint32_t s_stack[STACK_MAX * BLOCK];
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(BLOCK, 3) void extend_kernel(DScene S, PathState ps
 #ifdef RT_PHASE_STATS
             s_lane_iters[threadIdx.x] = 0u;
 #endif
-            traverse<MEDIA, false, true, true, !MEDIA>(S, root, r, 0, w, time, 0.001, b, stk, 0, &g, nn, np); // Interval::new(0.001, INFINITY) (camera.rs:258)
+            traverse<MEDIA, false, true, true, MEDIA == 0>(S, root, r, 0, w, time, 0.001, b, stk, 0, &g, nn, np); // Interval::new(0.001, INFINITY) (camera.rs:258)
             RT_PHASE(2);
 #ifdef RT_PHASE_STATS
             {
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(BLOCK, 2) void shade_kernel(DScene S, CamD cam, Pat
 // nearly empty.  Here a lane keeps its path and alternates traversal and shading until the path ends: the batch
 // then takes as long as its slowest path, not the sum over bounces of each bounce's slowest wave.  Same device
 // functions in the same order as extend_kernel + shade_kernel, so the same bits.
-template <bool MEDIA, bool TEXTURES, bool RR>
+template <int MEDIA, bool TEXTURES, bool RR>
 __global__ __launch_bounds__(BLOCK) void tail_kernel(DScene S, CamD cam, PathState ps, int qsel, unsigned long long seed, BatchGeom bg,
                                                      int first_bounce, int max_depth) {
     __shared__ uint32_t s_stack[STACK_MAX * BLOCK];
@@ -678,10 +678,12 @@ int pick_grid(rt_scene* s) {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, s->device));
     int per_cu = 0;
-    if (s->flat.has_medium) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, closest_hit_kernel<false, true, true>, BLOCK, 0));
+    if (s->flat.medium_depth > 1) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, closest_hit_kernel<false, true, 2>, BLOCK, 0));
+    else if (s->flat.has_medium) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, closest_hit_kernel<false, true, 1>, BLOCK, 0));
     else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, closest_hit_kernel<false, true, false>, BLOCK, 0));
     int per_cu2 = 0;
-    if (s->flat.has_medium) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, extend_kernel<true>, BLOCK, 0));
+    if (s->flat.medium_depth > 1) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, extend_kernel<2>, BLOCK, 0));
+    else if (s->flat.has_medium) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, extend_kernel<1>, BLOCK, 0));
     else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, extend_kernel<false>, BLOCK, 0));
     int per_cu3 = 0;
     // (grids are sized for the variants without the roulette rule; a render with the rule runs on the same grid)
@@ -691,7 +693,8 @@ int pick_grid(rt_scene* s) {
     s->extend_blocks = prop.multiProcessorCount * std::max(1, per_cu2);   // each kernel fills the chip at its own occupancy
     s->shade_blocks = prop.multiProcessorCount * std::max(1, per_cu3);
     int per_cu4 = 0;
-    if (s->flat.has_medium) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu4, tail_kernel<true, true, false>, BLOCK, 0));
+    if (s->flat.medium_depth > 1) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu4, tail_kernel<2, true, false>, BLOCK, 0));
+    else if (s->flat.has_medium) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu4, tail_kernel<1, true, false>, BLOCK, 0));
     else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu4, tail_kernel<false, true, false>, BLOCK, 0));
     s->tail_blocks = prop.multiProcessorCount * std::max(1, per_cu4);
     if (s->flat.fast_root != RT_REF_NONE) {
@@ -914,16 +917,21 @@ int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit
         hipLaunchKernelGGL(kernel, dim3(blocks), dim3(BLOCK), 0, st, s->dev, *rays, (unsigned long long)n, *hits, hit_ctx, (unsigned long long)seed, s->d_counters,
                            split ? 1 : 0, exact_cull ? 1 : 0);
     };
-    if (s->flat.has_medium) {
-        if (count && ordered) launch(closest_hit_kernel<true, true, true>);
-        else if (count) launch(closest_hit_kernel<true, false, true>);
-        else if (ordered) launch(closest_hit_kernel<false, true, true>);
-        else launch(closest_hit_kernel<false, false, true>);
+    if (s->flat.medium_depth > 1) {
+        if (count && ordered) launch(closest_hit_kernel<true, true, 2>);
+        else if (count) launch(closest_hit_kernel<true, false, 2>);
+        else if (ordered) launch(closest_hit_kernel<false, true, 2>);
+        else launch(closest_hit_kernel<false, false, 2>);
+    } else if (s->flat.has_medium) {
+        if (count && ordered) launch(closest_hit_kernel<true, true, 1>);
+        else if (count) launch(closest_hit_kernel<true, false, 1>);
+        else if (ordered) launch(closest_hit_kernel<false, true, 1>);
+        else launch(closest_hit_kernel<false, false, 1>);
     } else {
-        if (count && ordered) launch(closest_hit_kernel<true, true, false>);
-        else if (count) launch(closest_hit_kernel<true, false, false>);
-        else if (ordered) launch(closest_hit_kernel<false, true, false>);
-        else launch(closest_hit_kernel<false, false, false>);
+        if (count && ordered) launch(closest_hit_kernel<true, true, 0>);
+        else if (count) launch(closest_hit_kernel<true, false, 0>);
+        else if (ordered) launch(closest_hit_kernel<false, true, 0>);
+        else launch(closest_hit_kernel<false, false, 0>);
     }
     HIP_TRY(hipEventRecord(ev[2], st));
     hipLaunchKernelGGL(finalize_hits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s->dev, *rays, (unsigned long long)n, *hits, (const int32_t*)hit_ctx);
@@ -980,6 +988,7 @@ int render_impl(rt_scene* s, const rt_camera* cam, uint64_t seed, const rt_work*
             const bool fast_extend = s->flat.fast_root != RT_REF_NONE && s->tune.fast_extend;
             const bool has_tex = s->flat.has_textures || s->tune.shade_textures; // the switch forces the full shading code (A/B tests)
             const bool rr = cam->russian_roulette != 0;
+            const int media = s->flat.medium_depth > 1 ? 2 : (s->flat.has_medium ? 1 : 0);
             const uint64_t tail_paths = s->tune.tail_paths;
             const int k_refill = s->tune.refill, k_vote = s->tune.vote, k_chunk = s->tune.chunk;
             bool live_exact = true; // `live` is the device's count (it is refreshed only now and then)
@@ -987,10 +996,12 @@ int render_impl(rt_scene* s, const rt_camera* cam, uint64_t seed, const rt_work*
                 if (live_exact && bounce > 0 && live <= tail_paths) {
                     // few paths left: they finish in one launch, each lane following its path to the end
                     const int tblocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)s->tail_blocks, (live + BLOCK - 1) / BLOCK));
-                    auto tail = rr ? (s->flat.has_medium ? (has_tex ? tail_kernel<true, true, true> : tail_kernel<true, false, true>)
-                                                         : (has_tex ? tail_kernel<false, true, true> : tail_kernel<false, false, true>))
-                                   : (s->flat.has_medium ? (has_tex ? tail_kernel<true, true, false> : tail_kernel<true, false, false>)
-                                                         : (has_tex ? tail_kernel<false, true, false> : tail_kernel<false, false, false>));
+                    // (nested media: the full shading code whatever the textures, to keep the number of variants down)
+                    auto tail = media == 2 ? (rr ? tail_kernel<2, true, true> : tail_kernel<2, true, false>)
+                              : rr ? (media ? (has_tex ? tail_kernel<1, true, true> : tail_kernel<1, false, true>)
+                                            : (has_tex ? tail_kernel<0, true, true> : tail_kernel<0, false, true>))
+                                   : (media ? (has_tex ? tail_kernel<1, true, false> : tail_kernel<1, false, false>)
+                                            : (has_tex ? tail_kernel<0, true, false> : tail_kernel<0, false, false>));
                     hipLaunchKernelGGL(tail, dim3(tblocks), dim3(BLOCK), 0, st, s->dev, cd, ps, qsel, (unsigned long long)seed, bg, (int)bounce, (int)cam->max_depth);
                     s->counters.extend_launches += 1;
                     break;
@@ -1016,7 +1027,7 @@ int render_impl(rt_scene* s, const rt_camera* cam, uint64_t seed, const rt_work*
                 }
                 if (!fast_extend || s->flat.fast_partial) { // the whole world, or what follows its first member
                     if (fast_extend) hipLaunchKernelGGL(reset_work_kernel, dim3(1), dim3(1), 0, st, s->d_counters);
-                    hipLaunchKernelGGL(s->flat.has_medium ? extend_kernel<true> : extend_kernel<false>, dim3(blocks), dim3(BLOCK), 0, st, s->dev, ps, qsel,
+                    hipLaunchKernelGGL(media == 2 ? extend_kernel<2> : (media ? extend_kernel<1> : extend_kernel<0>), dim3(blocks), dim3(BLOCK), 0, st, s->dev, ps, qsel,
                                        (unsigned long long)seed, bg, cam->image_width, fast_extend ? 1 : 0);
                 }
                 hipLaunchKernelGGL(rr ? (has_tex ? shade_kernel<true, true> : shade_kernel<false, true>) : (has_tex ? shade_kernel<true, false> : shade_kernel<false, false>), dim3(sblocks), dim3(BLOCK), 0, st, s->dev, cd, ps, qsel, (unsigned long long)seed, bg, bounce == cam->max_depth - 1 ? 1 : 0);

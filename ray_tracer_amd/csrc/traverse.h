@@ -165,7 +165,9 @@ __shared__ uint32_t s_lane_iters[256]; // loop iterations of each lane's current
 // axis_order (exact nodes only): enter the child on the ray's near side of the node's split axis first.  Every box is
 // still tested by slab_test exactly as the reference does; only the order of two siblings changes, which can change
 // nothing but which of several primitives hit at exactly equal t is reported.
-template <bool TOP, bool COUNT, bool ORDERED, bool WAVE_LISTS = true, bool KEEP_ENTRY_RAY = WAVE_LISTS>
+// MEDIA: levels of constant media the walk resolves: 0 none in the scene, 1 media whose boundaries hold none, 2 a
+// medium inside the boundary of a medium (the boundary walks of level k are walks of level k - 1).
+template <int MEDIA, bool COUNT, bool ORDERED, bool WAVE_LISTS = true, bool KEEP_ENTRY_RAY = WAVE_LISTS>
 __device__ __forceinline__ void traverse(const DScene& S, uint32_t root, RayD ray, int32_t ctx, const WorldRay& w,
                                          double time, double tmin, Best& best, uint32_t* stk, int sp0, Rng* rng,
                                          uint32_t& n_nodes, uint32_t& n_prims, bool axis_order = false) {
@@ -175,7 +177,7 @@ __device__ __forceinline__ void traverse(const DScene& S, uint32_t root, RayD ra
     const int32_t entry_ctx = ctx;
     for (;;) {
 #ifdef RT_PHASE_STATS
-        if (TOP) s_lane_iters[threadIdx.x] += 1u;
+        if (MEDIA) s_lane_iters[threadIdx.x] += 1u;
 #endif
         const uint32_t kind = cur >> 28, idx = cur & 0x0FFFFFFFu;
         bool pop = true;
@@ -384,7 +386,7 @@ __device__ __forceinline__ void traverse(const DScene& S, uint32_t root, RayD ra
             else ray_in_context(S, w, ctx, ray);
             RT_STEP_END(4);
         } else if (kind == RT_REF_MEDIUM) {
-            if constexpr (TOP) { // ConstantMedium::hit (constant_medium.rs:48-104)
+            if constexpr (MEDIA > 0) { // ConstantMedium::hit (constant_medium.rs:48-104)
                 const DMedium m = S.media[idx];
                 if (COUNT) ++n_prims;
                 double t1 = 0.0, t2 = 0.0;
@@ -392,7 +394,8 @@ __device__ __forceinline__ void traverse(const DScene& S, uint32_t root, RayD ra
                 for (int pass = 0; pass < 2 && ok; ++pass) {
                     Best b; b.t = D_INF; b.ref = RT_REF_NONE; b.ctx = 0;
                     double lo = pass == 0 ? -D_INF : t1 + 0.0001; // Interval::UNIVERSE, then [rec1.t + 0.0001, inf)
-                    traverse<false, COUNT, ORDERED, WAVE_LISTS, KEEP_ENTRY_RAY>(S, m.boundary, ray, ctx, w, time, lo, b, stk, sp, nullptr, n_nodes, n_prims, axis_order);
+                    // (a medium inside the boundary draws from the same stream, once per boundary walk, as boundary.hit does)
+                    traverse<MEDIA - 1, COUNT, ORDERED, WAVE_LISTS, KEEP_ENTRY_RAY>(S, m.boundary, ray, ctx, w, time, lo, b, stk, sp, rng, n_nodes, n_prims, axis_order);
                     if (b.ref == RT_REF_NONE) ok = false;
                     else if (pass == 0) t1 = b.t; else t2 = b.t;
                 }

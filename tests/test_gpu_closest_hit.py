@@ -160,6 +160,31 @@ def test_book2_scene_with_media():
     compare(desc, o2, d2, time=tm[:30000], seed=78, min_hits=15000)
 
 
+def test_medium_inside_the_boundary_of_a_medium():
+    """constant_medium.rs:48-104 takes any Hittable as the boundary, another medium or a list holding one included:
+    the outer medium's two boundary walks then each draw for the inner one, from the same stream, in the order the
+    recursion does."""
+    m = rt.Lambertian(rt.Color(.5, .5, .5))
+    inner = rt.ConstantMedium.new_with_color(rt.Sphere(rt.Point3(0, 0, 0), 1.0, m), 1.5, rt.Color(1, 1, 1))
+    shell = rt.HittableList()
+    shell.add(inner)
+    shell.add(rt.Sphere(rt.Point3(0.3, 0, 0), 1.6, rt.Dielectric(1.5)))
+    outer = rt.ConstantMedium.new_with_color(shell, 0.8, rt.Color(.2, .4, .9))
+    world = rt.HittableList()
+    world.add(outer)
+    world.add(rt.Sphere(rt.Point3(0, -101.5, 0), 100.0, m))
+    world.add(rt.ConstantMedium.new_with_color(rt.Translate(rt.RotateY(inner, 20.0), rt.Vec3(3.0, 0, 0)), 2.0, rt.Color(1, 1, 1)))
+    desc = rt.SceneDesc.from_world(world)
+    o, d, tm = scenes.incoherent_rays(30000, [-3, 5, -2, 2, -3, 3], seed=51)
+    for flags in (0, F.RT_HIT_ORDERED):
+        res = compare(desc, o, d, time=tm, seed=9, min_hits=5000, flags=flags)
+    lst = rt.HittableList()
+    for k in range(40):
+        lst.add(rt.Sphere(rt.Point3(0.4 * k - 8.0, 0.0, 0.0), 0.15, m))
+    lst.add(outer)
+    compare(rt.SceneDesc.from_world(rt.BvhNode(lst)), o, d, time=tm, seed=10, min_hits=3000, flags=F.RT_HIT_ORDERED)
+
+
 def test_cornell_smoke_media_inside_bvh():
     world, lights, cam = scenes.cornell_smoke()
     desc = rt.SceneDesc.from_world(world, lights)

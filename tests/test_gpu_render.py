@@ -111,6 +111,24 @@ def test_cornell_smoke():
     check(c, a, b)
 
 
+def _nested_fog():
+    """Cornell smoke with one block's fog held inside a larger, thinner fog (a medium within a medium's boundary)."""
+    world, lights, cam = scenes.cornell_smoke()
+    glass = rt.Dielectric(1.5)
+    inner = rt.ConstantMedium.new_with_color(rt.Sphere(rt.Point3(278.0, 278.0, 278.0), 90.0, glass), 0.02, rt.Color(.9, .9, .9))
+    shell = rt.HittableList()
+    shell.add(inner)
+    shell.add(rt.Sphere(rt.Point3(278.0, 278.0, 278.0), 150.0, glass))
+    world.add(rt.ConstantMedium.new_with_color(shell, 0.004, rt.Color(.3, .5, .9)))
+    return world, lights, cam
+
+
+def test_nested_media_render():
+    cam, c, a, b, stats, ctr, gpu = render_both(_nested_fog, 40, 9, 30, seed=11)
+    check(c, a, b)
+    assert_same_ray_count(ctr.render_rays, stats["rays"])
+
+
 def test_texture_scenes():
     for build in (scenes.checkered_spheres, scenes.earth, scenes.perlin_spheres, scenes.simple_light, scenes.quads,
                   scenes.for_output13, scenes.test_triangle):
