@@ -214,6 +214,11 @@ def _roofline(args, n, dev_ms, box_tests, prim_tests, cpu, o, d, tm, np):
          "ref_order_nodes_per_ray": ref_nodes, "ref_order_prims_per_ray": ref_prims, "ref_order_bytes_per_ray": ref_bytes,
          "ref_order_equivalent_gbs": ref_bytes * n / (kernel_ms * 1e-3) / 1e9, "visit_reduction": ref_bytes / own_bytes,
          "count_sample_rays": m}
+    if ordered:
+        # what the kernel's own record formats ask for: 48-byte packed nodes, 80 bytes of a triangle's line (vertices and
+        # index), the 128-byte prepared ray, 12 bytes of (t, primitive) out
+        r["requested_bytes_per_ray"] = 48 * node_visits + 80 * prim_tests + 128 + 12
+        r["requested_gbs"] = r["requested_bytes_per_ray"] * n / (kernel_ms * 1e-3) / 1e9
     prof = _profile_for_this_build()
     if prof:
         # fabric-side bytes per launch from the rocprofv3 --pmc passes of the same command (profiles/), valid for this

@@ -23,7 +23,7 @@ def short(name):
     return None
 
 
-stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+stats = sorted(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)[-1]
 shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats.csv"))
 time_ms, calls = {}, {}
 for row in csv.DictReader(open(stats)):
@@ -32,7 +32,10 @@ for row in csv.DictReader(open(stats)):
         time_ms[k] = time_ms.get(k, 0.0) + float(row["TotalDurationNs"]) / 1e6
         calls[k] = calls.get(k, 0) + int(row["Calls"])
 tot = {}
+passes = {}
 for f in glob.glob(os.path.join(src, "*", "*", "*_counter_collection.csv")):
+    passes.setdefault(os.path.dirname(f), []).append(f)
+for f in [sorted(files, key=os.path.getmtime)[-1] for files in passes.values()]:  # only the last run of each pass
     for row in csv.DictReader(open(f)):
         k = short(row["Kernel_Name"])
         if k:

@@ -15,7 +15,8 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out")
 dst = os.path.join(root, "profiles")
 
-stats = glob.glob(os.path.join(src, f"{tag}_trace", "*", "*_kernel_stats.csv"))
+newest = lambda files: sorted(files, key=os.path.getmtime)[-1:]  # gpurun merges results into what earlier calls left: only the last run of a pass counts
+stats = newest(glob.glob(os.path.join(src, f"{tag}_trace", "*", "*_kernel_stats.csv")))
 avg_ns = None
 if stats:
     shutil.copy(stats[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
@@ -25,7 +26,10 @@ if stats:
 
 vals = {}
 for d in (f"{tag}_pmc", f"{tag}_pmc_mem"):
+    passes = {}
     for f in glob.glob(os.path.join(src, d, "*", "*", "*_counter_collection.csv")):
+        passes.setdefault(os.path.dirname(f), []).append(f)
+    for f in [g for files in passes.values() for g in newest(files)]:
         for row in csv.DictReader(open(f)):
             if kernel in row["Kernel_Name"] and "false" in row["Kernel_Name"]:
                 vals.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
