@@ -21,6 +21,7 @@
 #ifndef RT_BVH_KERNEL_H
 #define RT_BVH_KERNEL_H
 
+#include <type_traits>
 #include "traverse.h"
 #include "reorder.h"
 
@@ -50,11 +51,14 @@ constexpr int FAST_WAVES = FAST_BLOCK / 64;
 // The LDS array is indexed directly (never through a pointer kept in a struct) so every access
 // is compiled as a ds_ instruction rather than a flat one.
 struct LaneStack {
-    uint2* spill;              // this lane's column: entry k at spill[k * spill_stride]
+    uint2* spill;              // the launch's spill area: this lane's column starts at spill[column()], entry k at + k * spill_stride
     size_t spill_stride;
     int sp;                    // entries on the stack
     int base;                  // oldest entry still in LDS
 };
+// The column index is rebuilt where a spill happens (rarely) instead of living in two registers for the whole kernel;
+// the empty asm keeps the compiler from hoisting the address out of the branch again.
+#define RT_STACK_COLUMN(out) do { uint32_t t_ = threadIdx.x; asm volatile("" : "+v"(t_)); (out) = (size_t)blockIdx.x * FAST_BLOCK + t_; } while (0)
 #define RT_STACK_SLOT(k) s_fast_stack[((k) & (LDS_STACK - 1)) * FAST_BLOCK + threadIdx.x]
 #define RT_STACK_RESET(st) do { (st).sp = 0; (st).base = 0; } while (0)
 // Room for k more entries (k <= 3): the oldest LDS entries move to the lane's HBM column.  Checked once per node
@@ -62,7 +66,9 @@ struct LaneStack {
 #define RT_STACK_RESERVE(st, k)                                                               \
     do {                                                                                      \
         while ((st).sp - (st).base + (k) > LDS_STACK) {                                       \
-            (st).spill[(size_t)(st).base * (st).spill_stride] = RT_STACK_SLOT((st).base);     \
+            size_t col_;                                                                      \
+            RT_STACK_COLUMN(col_);                                                            \
+            (st).spill[col_ + (size_t)(st).base * (st).spill_stride] = RT_STACK_SLOT((st).base); \
             ++(st).base;                                                                      \
         }                                                                                     \
     } while (0)
@@ -83,7 +89,12 @@ struct LaneStack {
         --(st).sp;                                                                            \
         (out) = RT_STACK_SLOT((st).sp);                                                       \
         asm volatile("" : "+v"((out).x), "+v"((out).y));                                      \
-        if ((st).sp < (st).base) { (st).base = (st).sp; (out) = (st).spill[(size_t)(st).sp * (st).spill_stride]; } \
+        if ((st).sp < (st).base) {                                                            \
+            size_t col_;                                                                      \
+            RT_STACK_COLUMN(col_);                                                            \
+            (st).base = (st).sp;                                                              \
+            (out) = (st).spill[col_ + (size_t)(st).sp * (st).spill_stride];                   \
+        }                                                                                     \
     } while (0)
 
 
@@ -118,10 +129,9 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, 
     __shared__ uint2 s_fast_stack[LDS_STACK * FAST_BLOCK];
     LaneStack st;
     st.spill_stride = (size_t)gridDim.x * FAST_BLOCK;
-    st.spill = spill + (size_t)blockIdx.x * FAST_BLOCK + threadIdx.x;
+    st.spill = spill;
     RT_STACK_RESET(st);
     const uint32_t lane = threadIdx.x & 63u;
-    const unsigned long long lane_below = (1ull << lane) - 1ull;
     const unsigned long long n = rq.count ? *rq.count : n_in;
     // rays a wave takes from the global counter at a time: large enough to make the counter cheap, small
     // enough that every launched wave gets several chunks (chunk_in > 0 overrides, for measurements)
@@ -153,9 +163,18 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, 
     RayD r;
     Ray32 q;
     float tmin32 = 0.0f, best32 = 0.0f;
+    // The packed tree is only used with the default lower end of the interval (the host sees to it: its sort keys need
+    // tmin >= 0), the same for every ray: it stays in scalar registers.
+    const float tmin32_default = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(f32_round_down(tmin_default))));
     double time = 0.0, tmin = 0.0, best_t = 0.0;
     uint32_t best_ref = RT_REF_NONE, cur = 0, pend = RT_REF_NONE;
-    unsigned long long ray_slot = 0;
+    // (where the result goes: an index of the caller's batch; 32 bits unless the batch is addressed directly, RS == 1 without
+    // a prepared copy, and may hold more than 2^32 rays)
+    typedef typename std::conditional<PREP || RS != 1, uint32_t, unsigned long long>::type slot_t;
+    slot_t ray_slot = 0;
+    // a 32-bit slot waits in LDS from the refill to the end of its ray: written once, read once
+    constexpr bool SLOT_IN_LDS = sizeof(slot_t) == 4;
+    __shared__ uint32_t s_slot[SLOT_IN_LDS ? FAST_BLOCK : 1];
     uint32_t nn = 0, np = 0;
     // wave-level occupancy diagnostics (COUNT builds only): how many lanes take part in each phase
     unsigned long long c_refill = 0, c_node = 0, c_leaf = 0, c_pop = 0, c_mark = 0; // wave cycles per phase (s_memtime)
@@ -175,15 +194,15 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, 
                     const int leader = __ffsll((long long)idle) - 1;
                     unsigned long long base = 0;
                     if ((int)lane == leader) base = atomicAdd(my_counter, 1ull);
-                    const uint32_t blo = (uint32_t)__shfl((int)(uint32_t)base, leader);
-                    const uint32_t bhi = (uint32_t)__shfl((int)(uint32_t)(base >> 32), leader);
+                    const uint32_t blo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)base, leader); // into scalar registers: the range is the wave's
+                    const uint32_t bhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(base >> 32), leader);
                     wave_next = (waves_total + work_slot + (unsigned long long)work_slots * (((unsigned long long)bhi << 32) | blo)) * (unsigned long long)chunk;
                     wave_end = wave_next + (unsigned long long)chunk;
                     if (wave_end > n) wave_end = n;
                     if (wave_next >= n) { wave_next = wave_end = n; more = false; }
                 }
                 if (!active) {
-                    const unsigned long long qi = wave_next + (unsigned long long)__popcll(idle & lane_below);
+                    const unsigned long long qi = wave_next + (unsigned long long)__builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u)); // idle lanes below this one
                     if (PREP) {
                         if (qi < wave_end) {
                             const PRay p = prep[qi]; // one line, eight 16-byte loads
@@ -195,7 +214,7 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, 
                             tmin32 = p.tmin32; best32 = p.tmax32;
                             best_ref = RT_REF_NONE;
                             pend = RT_REF_NONE;
-                            ray_slot = p.idx;
+                            if (SLOT_IN_LDS) s_slot[threadIdx.x] = p.idx; else ray_slot = (slot_t)p.idx;
                             cur = root;
                             RT_STACK_RESET(st);
                             active = true;
@@ -216,7 +235,7 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, 
                         best32 = f32_round_up(best_t);
                         best_ref = RT_REF_NONE;
                         pend = RT_REF_NONE;
-                        ray_slot = i;
+                        if (SLOT_IN_LDS) s_slot[threadIdx.x] = (uint32_t)i; else ray_slot = (slot_t)i;
                         cur = root;
                         RT_STACK_RESET(st);
                         active = true;
@@ -305,7 +324,7 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, 
                     uint32_t k[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float tn = fmaxf(fmaxf(__builtin_fmaf(nx[j], ax, bnx), __builtin_fmaf(ny[j], ay, bny)), fmaxf(__builtin_fmaf(nz[j], az, bnz), tmin32));
+                        const float tn = fmaxf(fmaxf(__builtin_fmaf(nx[j], ax, bnx), __builtin_fmaf(ny[j], ay, bny)), fmaxf(__builtin_fmaf(nz[j], az, bnz), tmin32_default));
                         const float tf = fminf(fminf(__builtin_fmaf(fx[j], ax, bfx), __builtin_fmaf(fy[j], ay, bfy)), fminf(__builtin_fmaf(fz[j], az, bfz), best32));
                         const bool hit = (tn <= tf) && ((uint32_t)j < n_all);
                         k[j] = hit ? ((__float_as_uint(tn) & ~3u) | (uint32_t)j) : 0xFFFFFFFFu;
@@ -386,7 +405,7 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, 
                         if (COUNT) ++np;
                         const uint32_t orig = tp->orig; // rides in the request that brings v2.z
                         double t, u, v;
-                        if (tri_test(d3p(tp->v0), d3p(tp->v1), d3p(tp->v2), r, tmin, best_t, t, u, v)) { best_t = t; best_ref = make_ref(RT_REF_TRI, orig); best32 = f32_round_up(t); }
+                        if (tri_test(d3p(tp->v0), d3p(tp->v1), d3p(tp->v2), r, tmin_default, best_t, t, u, v)) { best_t = t; best_ref = make_ref(RT_REF_TRI, orig); best32 = f32_round_up(t); }
                     } else if (PRIM == RT_REF_TRI || (PRIM == 0 && kind == RT_REF_TRI)) {
                         const DTri* tp = S.tris + idx;
                         if (COUNT) ++np;
@@ -417,8 +436,10 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, 
                 for (int trip = 0; trip < POP_TRIPS; ++trip) {
                     if (st.sp == 0) {
                         if (pend != RT_REF_NONE) break; // the ray's last primitive is still to be tested
-                        out_t[ray_slot * OUT_T_STRIDE] = best_ref == RT_REF_NONE ? D_INF : best_t;
-                        out_prim[ray_slot * OUT_PRIM_STRIDE] = best_ref;
+                        slot_t slot = SLOT_IN_LDS ? (slot_t)s_slot[threadIdx.x] : ray_slot;
+                        asm volatile("" : "+v"(slot)); // the two addresses are formed here, once per ray, not kept in registers from the refill on
+                        out_t[(unsigned long long)slot * OUT_T_STRIDE] = best_ref == RT_REF_NONE ? D_INF : best_t;
+                        out_prim[(unsigned long long)slot * OUT_PRIM_STRIDE] = best_ref;
                         active = false;
                         pop = false;
                         break;
