@@ -56,6 +56,7 @@ def main() -> None:
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-render", action="store_true", help="skip the camera-samples/s figures (second half of the metric)")
     ap.add_argument("--no-mesh", action="store_true", help="skip the closed-mesh closest-hit figure")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (nccl) and run the frame job even with one rank")
     ap.add_argument("--frame-strata", type=int, default=64, help="strata per rank of the multi-GPU frame sample (of 4096)")
     args = ap.parse_args()
 
@@ -74,7 +75,7 @@ def main() -> None:
     torch.cuda.set_device(local_rank)  # before any scene is created: a scene lives on the device current at rt_scene_create
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world_size > 1:
+    if world_size > 1 or args.force_dist:  # --force-dist: rehearse the RCCL path with a single rank under torch.distributed.run
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
@@ -182,7 +183,7 @@ def main() -> None:
         out["render"] = {name: _render_figure(rt, F, scenes, np, name, with_cpu=not args.no_cpu) for name in ("book2_final", "cornell_box")}
 
     # ------------------------------------------------------------------ the frame partitioned over the ranks + one reduce
-    if world_size > 1 and not args.no_render:
+    if dist is not None and not args.no_render:
         fig = _multi_gpu_render(rt, F, scenes, parallel, torch, dist, dev, stream, args.frame_strata * world_size)
         if rank == 0:
             out["multi_gpu_render"] = fig
