@@ -248,7 +248,9 @@ typedef struct rt_hit_batch {
     double*   t;      /* HitRecord.t; +infinity where nothing was hit */
     uint32_t* prim;   /* (kind << 28) | index of the primitive in the description, RT_REF_NONE on a miss;
                          kinds RT_REF_SPHERE / _QUAD / _TRI / _MEDIUM (index = object id of the medium) */
-    double*   u;      /* HitRecord.u, v (hittable.rs:19-20) */
+    double*   u;      /* HitRecord.u, v (hittable.rs:19-20).  A constant-medium hit never writes them in the reference
+                         (constant_medium.rs:96-101): reported as 0, except in scenes where a medium's phase function
+                         reads u,v (image texture), where they are what the reference's record would hold */
     double*   v;
     uint8_t*  front_face;
     int32_t*  mat;    /* material id of the hit */

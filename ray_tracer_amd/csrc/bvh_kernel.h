@@ -480,7 +480,10 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, 
 // Completes HitRecord fields for a batch whose (t, prim) are already written; `ctx`: transform context of every
 // hit (null: all in the world's own context).  prim is rewritten, because a constant medium is reported by its
 // object id, not by the internal reference the traversal leaves.
-__global__ __launch_bounds__(256) void finalize_hits_kernel(DScene S, rt_ray_batch rays, unsigned long long n, rt_hit_batch hits, const int32_t* ctx) {
+// keep_medium_uv: the traversal kernel has already written the u,v of constant-medium hits (scenes whose phase functions
+// read them: traverse.h UvTrack); otherwise a medium hit reports 0, 0.
+__global__ __launch_bounds__(256) void finalize_hits_kernel(DScene S, rt_ray_batch rays, unsigned long long n, rt_hit_batch hits, const int32_t* ctx,
+                                                            int keep_medium_uv) {
     const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t prim = hits.prim[i];
@@ -503,8 +506,9 @@ __global__ __launch_bounds__(256) void finalize_hits_kernel(DScene S, rt_ray_bat
     HitRec h;
     finalize(S, w, rays.time ? rays.time[i] : 0.0, b, h);
     hits.prim[i] = h.prim;
-    if (hits.u) hits.u[i] = h.u;
-    if (hits.v) hits.v[i] = h.v;
+    const bool keep_uv = keep_medium_uv && (prim >> 28) == RT_REF_MEDIUM;
+    if (hits.u && !keep_uv) hits.u[i] = h.u;
+    if (hits.v && !keep_uv) hits.v[i] = h.v;
     if (hits.front_face) hits.front_face[i] = h.front_face ? 1 : 0;
     if (hits.mat) hits.mat[i] = h.mat;
     if (hits.nx) hits.nx[i] = h.normal.x;

@@ -19,6 +19,7 @@ constexpr uint32_t REF_POPX = 9u;      // leave a transform: restore context `in
 constexpr uint32_t REF_QUADS = 10u;    // a list that is nothing but 2..16 consecutive quads (the six sides of a box): index =
                                        // (count - 1) << 24 | first quad; stands in for the list in the 4-wide nodes, so the
                                        // walk needs neither the list header nor its items
+constexpr uint32_t REF_LISTEND = 11u;  // (record-history walks only) the list entered below is done: settle whose u,v the enclosing record holds
 constexpr uint32_t REF_OTHER = 15u;    // light-list member without pdf_value/random (hittable.rs:51-56 defaults)
 
 constexpr int STACK_MAX = 32;          // traversal stack entries per lane (LDS)

@@ -397,9 +397,9 @@ struct Flattener {
                 if (!child_ok(o.a)) return fail(RT_E_INVALID, "constant_medium: bad boundary");
                 if (!mat_ok(o.mat)) return fail(RT_E_INVALID, "constant_medium: material out of range");
                 if (obj_medium[o.a] >= 2) return fail(RT_E_UNSUPPORTED, "constant_medium: media nested more than two deep are not supported");
-                if (d->materials[o.mat].kind == RT_MAT_ISOTROPIC && texture_uses_uv(d->materials[o.mat].tex))
-                    return fail(RT_E_UNSUPPORTED, "constant_medium: the reference never writes u,v for a medium hit (constant_medium.rs:96-101); "
-                                                  "a phase function with an image texture would read stale values and is not supported");
+                // the reference never writes u,v for a medium hit (constant_medium.rs:96-101): a phase function over an image
+                // texture reads what the record held before, which the kernels then have to keep track of
+                if (d->materials[o.mat].tex >= 0 && texture_uses_uv(d->materials[o.mat].tex)) f.track_uv = true;
                 b = f.object_bounds[o.a];
                 obj_medium[i] = (uint8_t)(1 + obj_medium[o.a]);
                 f.medium_depth = std::max(f.medium_depth, (int)obj_medium[i]);
@@ -850,7 +850,7 @@ struct Flattener {
                 if (rk == RT_REF_SPHERE || rk == RT_REF_QUAD || rk == RT_REF_TRI) continue;
                 m = std::max(m, need(r));
             }
-            return 2 + m;
+            return (f.track_uv ? 8 : 2) + m; // continuation (2), and with record history the caller's u,v source and the end marker (6)
         }
         case RT_REF_XFORM: return 1 + need(f.xforms[idx].child);
         case RT_REF_MEDIUM: return need(f.media[idx].boundary);
@@ -903,7 +903,9 @@ struct Flattener {
             f.n_lights = -1;
         }
         int64_t hoisted_root = -1;
-        if (int rc2 = hoist_first_member(hoisted_root)) return rc2;
+        // (with record history the world list is walked as declared: its first member's hit is part of that history)
+        if (!f.track_uv)
+            if (int rc2 = hoist_first_member(hoisted_root)) return rc2;
         // 4-wide copies of every BVH that holds no constant medium and has finite bounds (ordered traversal)
         f.qnodes.reserve(f.nodes.size() / 2 + 16);
         for (uint32_t root : bvh_roots) {

@@ -52,6 +52,7 @@ struct FlatScene {
                                       // triangle boxes a random line through the scene's box crosses
     double quant_inflation = 0.0;     // mean surface-area ratio of the 8-bit child boxes to their f32 boxes
     bool has_medium = false;
+    bool track_uv = false;            // some constant medium's phase function reads u,v: traversal keeps the record history (traverse.h UvTrack)
     int medium_depth = 0;             // 2: some medium's boundary holds a medium (constant_medium.rs:48-104 takes any Hittable)
     bool uses_uv = false;             // an image texture exists: shading needs the spheres' (u,v)
     bool has_textures = false;        // some material's texture is not a solid colour (checker, image, noise)

@@ -77,6 +77,7 @@ struct PathState {
     PathRec* rec;
     uint32_t* queue[2];
     unsigned long long* counters;
+    double2* uv;   // per path: the u,v a constant-medium hit reports (null unless some phase function reads them: traverse.h UvTrack)
 };
 
 // The world ray of path p as the traversal and the record completion read it (strided view of the records).
@@ -141,8 +142,20 @@ struct WaveWork {
     }
 };
 
-// MEDIA = false: the scene holds no constant medium; the nested boundary queries and the random draw are compiled out.
-template <bool COUNT, bool ORDERED, int MEDIA>
+// u,v of the record a medium hit was written into: those of the primitive hit that last wrote it, or the default 0, 0.
+__device__ __forceinline__ void stale_uv(const DScene& S, const WorldRay& w, double time, const UvTrack& uvt, double& u, double& v) {
+    u = 0.0; v = 0.0;
+    if (uvt.ref == RT_REF_NONE) return;
+    Best b;
+    b.t = uvt.t; b.ref = uvt.ref; b.ctx = uvt.ctx;
+    HitRec h;
+    finalize(S, w, time, b, h, true);
+    u = h.u; v = h.v;
+}
+
+// MEDIA = 0: the scene holds no constant medium; the nested boundary queries and the random draw are compiled out.
+// UV: some phase function reads u,v, so the walk keeps track of whose u,v a medium hit inherits (traverse.h UvTrack).
+template <bool COUNT, bool ORDERED, int MEDIA, bool UV = false>
 __global__ __launch_bounds__(BLOCK) void closest_hit_kernel(DScene S, rt_ray_batch rays, unsigned long long n, rt_hit_batch hits,
                                                             int32_t* hit_ctx, unsigned long long seed, unsigned long long* counters, int rest_only,
                                                             int axis_order) {
@@ -173,7 +186,15 @@ __global__ __launch_bounds__(BLOCK) void closest_hit_kernel(DScene S, rt_ray_bat
                 if (first_hit != RT_REF_NONE) { b.t = hits.t[i]; b.ref = first_hit; }
                 root = S.world_rest;
             }
-            traverse<MEDIA, COUNT, ORDERED>(S, root, r, 0, w, time, tmin, b, stk, 0, &g, nn, np, axis_order != 0);
+            UvTrack uvt;
+            uvt.ref = RT_REF_NONE; uvt.ctx = 0; uvt.t = 0.0; uvt.any = false;
+            traverse<MEDIA, COUNT, ORDERED, true, true, UV>(S, root, r, 0, w, time, tmin, b, stk, 0, &g, nn, np, axis_order != 0, &uvt);
+            if (UV && b.ref != RT_REF_NONE && (b.ref >> 28) == RT_REF_MEDIUM) { // finalize_hits_kernel leaves these two alone
+                double u, v;
+                stale_uv(S, w, time, uvt, u, v);
+                if (hits.u) hits.u[i] = u;
+                if (hits.v) hits.v[i] = v;
+            }
             // (t, what was hit, in which transform context): finalize_hits_kernel completes the record in a pass of
             // its own, which keeps the record arithmetic (acos, atan2, the transform unwinding) out of this
             // kernel's register budget
@@ -251,7 +272,7 @@ __global__ __launch_bounds__(BLOCK) void raygen_kernel(CamD cam, BatchGeom bg, P
 // traversal are compiled out (fewer registers, one more wave per SIMD).
 // At least 3 waves per SIMD (168 registers): the variant with media sits within a few registers of that limit,
 // and one wave less costs it more than 10 %.
-template <int MEDIA>
+template <int MEDIA, bool UV = false>
 __global__ __launch_bounds__(BLOCK, 3) void extend_kernel(DScene S, PathState ps, int qsel, unsigned long long seed, BatchGeom bg, int32_t image_width,
                                                           int rest_only) {
     __shared__ uint32_t s_stack[STACK_MAX * BLOCK];
@@ -304,7 +325,14 @@ __global__ __launch_bounds__(BLOCK, 3) void extend_kernel(DScene S, PathState ps
 #ifdef RT_PHASE_STATS
             s_lane_iters[threadIdx.x] = 0u;
 #endif
-            traverse<MEDIA, false, true, true, MEDIA == 0>(S, root, r, 0, w, time, 0.001, b, stk, 0, &g, nn, np); // Interval::new(0.001, INFINITY) (camera.rs:258)
+            UvTrack uvt;
+            uvt.ref = RT_REF_NONE; uvt.ctx = 0; uvt.t = 0.0; uvt.any = false;
+            traverse<MEDIA, false, true, true, MEDIA == 0, UV>(S, root, r, 0, w, time, 0.001, b, stk, 0, &g, nn, np, false, &uvt); // Interval::new(0.001, INFINITY) (camera.rs:258)
+            if (UV && b.ref != RT_REF_NONE && (b.ref >> 28) == RT_REF_MEDIUM) {
+                double2 uv;
+                stale_uv(S, w, time, uvt, uv.x, uv.y);
+                ps.uv[p] = uv;
+            }
             RT_PHASE(2);
 #ifdef RT_PHASE_STATS
             {
@@ -393,6 +421,10 @@ __global__ __launch_bounds__(BLOCK, 2) void shade_kernel(DScene S, CamD cam, Pat
                     double time = rec->time;
                     HitRec h;
                     finalize(S, wr, time, b, h, TEXTURES && S.uses_uv != 0u); // only an image texture reads u,v (texture.rs:88-107)
+                    if (TEXTURES && ps.uv && (b.ref >> 28) == RT_REF_MEDIUM) { // a medium hit reports the u,v its record held (extend_kernel left them here)
+                        const double2 uv = ps.uv[p];
+                        h.u = uv.x; h.v = uv.y;
+                    }
                     RT_PHASE(1);
                     uint32_t s_local = p / bg.npix, pix = p - s_local * bg.npix;
                     int32_t i = bg.x0 + (int32_t)(pix % (uint32_t)bg.tw);
@@ -447,7 +479,7 @@ __global__ __launch_bounds__(BLOCK, 2) void shade_kernel(DScene S, CamD cam, Pat
 // nearly empty.  Here a lane keeps its path and alternates traversal and shading until the path ends: the batch
 // then takes as long as its slowest path, not the sum over bounces of each bounce's slowest wave.  Same device
 // functions in the same order as extend_kernel + shade_kernel, so the same bits.
-template <int MEDIA, bool TEXTURES, bool RR>
+template <int MEDIA, bool TEXTURES, bool RR, bool UV = false>
 __global__ __launch_bounds__(BLOCK) void tail_kernel(DScene S, CamD cam, PathState ps, int qsel, unsigned long long seed, BatchGeom bg,
                                                      int first_bounce, int max_depth) {
     __shared__ uint32_t s_stack[STACK_MAX * BLOCK];
@@ -475,7 +507,9 @@ __global__ __launch_bounds__(BLOCK) void tail_kernel(DScene S, CamD cam, PathSta
             set_inverse(r);
             Best b;
             b.t = D_INF; b.ref = RT_REF_NONE; b.ctx = 0;
-            traverse<MEDIA, false, true, true, false>(S, S.world, r, 0, w, time, 0.001, b, stk, 0, &g, nn, np); // Interval::new(0.001, INFINITY) (camera.rs:258)
+            UvTrack uvt;
+            uvt.ref = RT_REF_NONE; uvt.ctx = 0; uvt.t = 0.0; uvt.any = false;
+            traverse<MEDIA, false, true, true, false, UV>(S, S.world, r, 0, w, time, 0.001, b, stk, 0, &g, nn, np, false, &uvt); // Interval::new(0.001, INFINITY) (camera.rs:258)
             ++traced;
             if (b.ref == RT_REF_NONE) { // camera.rs:258-260
                 L = L + beta * d3p(cam.background);
@@ -483,6 +517,7 @@ __global__ __launch_bounds__(BLOCK) void tail_kernel(DScene S, CamD cam, PathSta
             }
             HitRec h;
             finalize(S, r, time, b, h, TEXTURES && S.uses_uv != 0u);
+            if (UV && (b.ref >> 28) == RT_REF_MEDIUM) stale_uv(S, w, time, uvt, h.u, h.v);
             D3 ray_dir = d3(r.dx, r.dy, r.dz);
             D3 nd;
             if (!shade_hit<TEXTURES, RR>(S, h, ray_dir, g, beta, L, nd)) break;
@@ -816,6 +851,8 @@ int ensure_workspace(rt_scene* s, uint64_t paths) {
     if ((rc = alloc(reinterpret_cast<void**>(&ps.rec), paths * sizeof(PathRec)))) return rc;
     if ((rc = alloc(reinterpret_cast<void**>(&ps.queue[0]), paths * sizeof(uint32_t)))) return rc;
     if ((rc = alloc(reinterpret_cast<void**>(&ps.queue[1]), paths * sizeof(uint32_t)))) return rc;
+    ps.uv = nullptr;
+    if (s->flat.track_uv && (rc = alloc(reinterpret_cast<void**>(&ps.uv), paths * sizeof(double2)))) return rc;
     ps.counters = s->d_counters;
     s->ws_paths = paths;
     return RT_OK;
@@ -888,7 +925,7 @@ int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev[2], st));
         if (hits->u || hits->v || hits->front_face || hits->mat || hits->nx || hits->ny || hits->nz || hits->px || hits->py || hits->pz)
-            hipLaunchKernelGGL(finalize_hits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s->dev, *rays, (unsigned long long)n, *hits, (const int32_t*)nullptr);
+            hipLaunchKernelGGL(finalize_hits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s->dev, *rays, (unsigned long long)n, *hits, (const int32_t*)nullptr, 0);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev[3], st)); // the whole call: reorder pass, traversal, record completion
         s->hit_reordered_at[s->hit_launches % HIT_RING] = reorder;
@@ -923,7 +960,12 @@ int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit
         hipLaunchKernelGGL(kernel, dim3(blocks), dim3(BLOCK), 0, st, s->dev, *rays, (unsigned long long)n, *hits, hit_ctx, (unsigned long long)seed, s->d_counters,
                            split ? 1 : 0, exact_cull ? 1 : 0);
     };
-    if (s->flat.medium_depth > 1) {
+    if (s->flat.track_uv) { // record history for a phase function that reads u,v: the two-level media variant serves every such scene
+        if (count && ordered) launch(closest_hit_kernel<true, true, 2, true>);
+        else if (count) launch(closest_hit_kernel<true, false, 2, true>);
+        else if (ordered) launch(closest_hit_kernel<false, true, 2, true>);
+        else launch(closest_hit_kernel<false, false, 2, true>);
+    } else if (s->flat.medium_depth > 1) {
         if (count && ordered) launch(closest_hit_kernel<true, true, 2>);
         else if (count) launch(closest_hit_kernel<true, false, 2>);
         else if (ordered) launch(closest_hit_kernel<false, true, 2>);
@@ -940,7 +982,7 @@ int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit
         else launch(closest_hit_kernel<false, false, 0>);
     }
     HIP_TRY(hipEventRecord(ev[2], st));
-    hipLaunchKernelGGL(finalize_hits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s->dev, *rays, (unsigned long long)n, *hits, (const int32_t*)hit_ctx);
+    hipLaunchKernelGGL(finalize_hits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s->dev, *rays, (unsigned long long)n, *hits, (const int32_t*)hit_ctx, s->flat.track_uv ? 1 : 0);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev[3], st));
     s->hit_reordered_at[s->hit_launches % HIT_RING] = false;
@@ -1003,7 +1045,8 @@ int render_impl(rt_scene* s, const rt_camera* cam, uint64_t seed, const rt_work*
                     // few paths left: they finish in one launch, each lane following its path to the end
                     const int tblocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)s->tail_blocks, (live + BLOCK - 1) / BLOCK));
                     // (nested media: the full shading code whatever the textures, to keep the number of variants down)
-                    auto tail = media == 2 ? (rr ? tail_kernel<2, true, true> : tail_kernel<2, true, false>)
+                    auto tail = s->flat.track_uv ? (rr ? tail_kernel<2, true, true, true> : tail_kernel<2, true, false, true>)
+                              : media == 2 ? (rr ? tail_kernel<2, true, true> : tail_kernel<2, true, false>)
                               : rr ? (media ? (has_tex ? tail_kernel<1, true, true> : tail_kernel<1, false, true>)
                                             : (has_tex ? tail_kernel<0, true, true> : tail_kernel<0, false, true>))
                                    : (media ? (has_tex ? tail_kernel<1, true, false> : tail_kernel<1, false, false>)
@@ -1033,7 +1076,9 @@ int render_impl(rt_scene* s, const rt_camera* cam, uint64_t seed, const rt_work*
                 }
                 if (!fast_extend || s->flat.fast_partial) { // the whole world, or what follows its first member
                     if (fast_extend) hipLaunchKernelGGL(reset_work_kernel, dim3(1), dim3(1), 0, st, s->d_counters);
-                    hipLaunchKernelGGL(media == 2 ? extend_kernel<2> : (media ? extend_kernel<1> : extend_kernel<0>), dim3(blocks), dim3(BLOCK), 0, st, s->dev, ps, qsel,
+                    auto extend = media == 2 ? extend_kernel<2> : (media ? extend_kernel<1> : extend_kernel<0>);
+                    if (s->flat.track_uv) extend = extend_kernel<2, true>;
+                    hipLaunchKernelGGL(extend, dim3(blocks), dim3(BLOCK), 0, st, s->dev, ps, qsel,
                                        (unsigned long long)seed, bg, cam->image_width, fast_extend ? 1 : 0);
                 }
                 hipLaunchKernelGGL(rr ? (has_tex ? shade_kernel<true, true> : shade_kernel<false, true>) : (has_tex ? shade_kernel<true, false> : shade_kernel<false, false>), dim3(sblocks), dim3(BLOCK), 0, st, s->dev, cd, ps, qsel, (unsigned long long)seed, bg, bounce == cam->max_depth - 1 ? 1 : 0);

@@ -162,15 +162,28 @@ __shared__ uint32_t s_lane_iters[256]; // loop iterations of each lane's current
 #define RT_STEP_END(k) do { } while (0)
 #endif
 
+// Whose surface coordinates the reference's HitRecord would hold.  ConstantMedium::hit writes t, p, normal,
+// front_face and mat but never u,v (constant_medium.rs:96-101), so a medium hit reports the u,v of the last primitive
+// that was written into the same record: HittableList::hit works on a record of its own (`temp_rec`, default u = v = 0)
+// and copies it out on every hit (hittable_list.rs:46-57); BvhNode, Translate and RotateY hand their caller's record
+// down.  Only a phase function over an image texture reads these values, so only scenes that have one pay for the
+// book-keeping (UV = true): the record of the current frame is named by the primitive hit that last wrote it.
+struct UvTrack {
+    uint32_t ref;  // RT_REF_NONE: the default record, u = v = 0
+    int32_t ctx;
+    double t;
+    bool any;      // something was hit since the current list frame was entered (the list will return true)
+};
+
 // axis_order (exact nodes only): enter the child on the ray's near side of the node's split axis first.  Every box is
 // still tested by slab_test exactly as the reference does; only the order of two siblings changes, which can change
 // nothing but which of several primitives hit at exactly equal t is reported.
 // MEDIA: levels of constant media the walk resolves: 0 none in the scene, 1 media whose boundaries hold none, 2 a
 // medium inside the boundary of a medium (the boundary walks of level k are walks of level k - 1).
-template <int MEDIA, bool COUNT, bool ORDERED, bool WAVE_LISTS = true, bool KEEP_ENTRY_RAY = WAVE_LISTS>
+template <int MEDIA, bool COUNT, bool ORDERED, bool WAVE_LISTS = true, bool KEEP_ENTRY_RAY = WAVE_LISTS, bool UV = false>
 __device__ __forceinline__ void traverse(const DScene& S, uint32_t root, RayD ray, int32_t ctx, const WorldRay& w,
                                          double time, double tmin, Best& best, uint32_t* stk, int sp0, Rng* rng,
-                                         uint32_t& n_nodes, uint32_t& n_prims, bool axis_order = false) {
+                                         uint32_t& n_nodes, uint32_t& n_prims, bool axis_order = false, UvTrack* uvt = nullptr) {
     int sp = sp0;
     uint32_t cur = root;
     const RayD entry_ray = ray;
@@ -182,6 +195,9 @@ __device__ __forceinline__ void traverse(const DScene& S, uint32_t root, RayD ra
         const uint32_t kind = cur >> 28, idx = cur & 0x0FFFFFFFu;
         bool pop = true;
         bool wide_done = false;
+        const double uv_t0 = best.t;          // (UV) the record before this step: a primitive that changes it becomes the
+        const uint32_t uv_ref0 = best.ref;    // source of the frame's u,v
+        const int32_t uv_ctx0 = best.ctx;
         if (ORDERED && kind == RT_REF_NODE) {
             RT_STEP_BEGIN();
             WNodeLoad wn;
@@ -295,8 +311,28 @@ __device__ __forceinline__ void traverse(const DScene& S, uint32_t root, RayD ra
                 if (k < count) test_primitive(S, make_ref(RT_REF_QUAD, first + k), ray, ctx, time, tmin, best);
             }
             RT_STEP_END(3);
+        } else if (UV && kind == REF_LISTEND) {
+            // HittableList::hit returns: its caller's record took a copy of temp_rec at every hit, so it now holds the
+            // list's u,v if the list hit anything, and what it held before otherwise
+            sp -= 5;
+            if (!uvt->any) {
+                uvt->ref = stk[sp * BLOCK];
+                uvt->ctx = (int32_t)stk[(sp + 1) * BLOCK];
+                uvt->t = __hiloint2double((int)stk[(sp + 3) * BLOCK], (int)stk[(sp + 2) * BLOCK]);
+            }
+            uvt->any = uvt->any || stk[(sp + 4) * BLOCK] != 0u;
         } else if (kind == RT_REF_LIST || kind == REF_LISTCONT) {
             RT_STEP_BEGIN();
+            if (UV && kind == RT_REF_LIST) { // a fresh temp_rec: remember the caller's, to be settled when the list is done
+                stk[sp * BLOCK] = uvt->ref;
+                stk[(sp + 1) * BLOCK] = (uint32_t)uvt->ctx;
+                stk[(sp + 2) * BLOCK] = (uint32_t)__double2loint(uvt->t);
+                stk[(sp + 3) * BLOCK] = (uint32_t)__double2hiint(uvt->t);
+                stk[(sp + 4) * BLOCK] = uvt->any ? 1u : 0u;
+                stk[(sp + 5) * BLOCK] = make_ref(REF_LISTEND, 0u);
+                sp += 6;
+                uvt->ref = RT_REF_NONE; uvt->any = false;
+            }
             uint32_t pos = 0;
             if (kind == REF_LISTCONT) { --sp; pos = stk[sp * BLOCK]; }
             bool walked = false;
@@ -395,7 +431,8 @@ __device__ __forceinline__ void traverse(const DScene& S, uint32_t root, RayD ra
                     Best b; b.t = D_INF; b.ref = RT_REF_NONE; b.ctx = 0;
                     double lo = pass == 0 ? -D_INF : t1 + 0.0001; // Interval::UNIVERSE, then [rec1.t + 0.0001, inf)
                     // (a medium inside the boundary draws from the same stream, once per boundary walk, as boundary.hit does)
-                    traverse<MEDIA - 1, COUNT, ORDERED, WAVE_LISTS, KEEP_ENTRY_RAY>(S, m.boundary, ray, ctx, w, time, lo, b, stk, sp, rng, n_nodes, n_prims, axis_order);
+                    // (rec1 / rec2 are records of their own and are dropped: no history to keep in the boundary walks)
+                    traverse<MEDIA - 1, COUNT, ORDERED, WAVE_LISTS, KEEP_ENTRY_RAY, false>(S, m.boundary, ray, ctx, w, time, lo, b, stk, sp, rng, n_nodes, n_prims, axis_order);
                     if (b.ref == RT_REF_NONE) ok = false;
                     else if (pass == 0) t1 = b.t; else t2 = b.t;
                 }
@@ -410,10 +447,14 @@ __device__ __forceinline__ void traverse(const DScene& S, uint32_t root, RayD ra
                         if (!(hit_distance > distance_inside_boundary)) {
                             best.t = rec1_t + hit_distance / ray_length;
                             best.ref = cur; best.ctx = ctx;
+                            if (UV) uvt->any = true; // a hit, but u,v stay as they are
                         }
                     }
                 }
             }
+        }
+        if (UV && kind != RT_REF_MEDIUM && kind != REF_LISTEND && (best.t != uv_t0 || best.ref != uv_ref0 || best.ctx != uv_ctx0)) {
+            uvt->ref = best.ref; uvt->ctx = best.ctx; uvt->t = best.t; uvt->any = true; // a primitive wrote the whole record
         }
         if (pop) {
             RT_STEP_BEGIN();

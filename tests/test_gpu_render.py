@@ -129,6 +129,26 @@ def test_nested_media_render():
     assert_same_ray_count(ctr.render_rays, stats["rays"])
 
 
+def _image_fog():
+    """Cornell smoke whose fogs scatter with an image texture: the texture is looked up at the u,v the hit record held
+    before the medium was hit (walls and box sides: quads write u,v; the default record: 0, 0)."""
+    world, lights, cam = scenes.cornell_smoke()
+    img = rt.ImageTexture(scenes.procedural_image())
+    world.add(rt.ConstantMedium.new_with_texture(rt.Sphere(rt.Point3(278.0, 400.0, 278.0), 100.0, rt.Dielectric(1.5)), 0.02, img))
+    bag = rt.HittableList()
+    bag.add(rt.Sphere(rt.Point3(150.0, 100.0, 150.0), 40.0, rt.Lambertian(rt.Color(.8, .3, .3))))
+    bag.add(rt.ConstantMedium.new_with_texture(rt.Sphere(rt.Point3(150.0, 100.0, 150.0), 90.0, rt.Dielectric(1.5)), 0.03, img))
+    world.add(bag)
+    return world, lights, cam
+
+
+def test_phase_function_over_an_image_texture():
+    for depth in (30, 6):  # 6: the tail kernel takes over early on so few paths
+        cam, c, a, b, stats, ctr, gpu = render_both(_image_fog, 40, 9, depth, seed=13)
+        check(c, a, b)
+        assert_same_ray_count(ctr.render_rays, stats["rays"])
+
+
 def test_texture_scenes():
     for build in (scenes.checkered_spheres, scenes.earth, scenes.perlin_spheres, scenes.simple_light, scenes.quads,
                   scenes.for_output13, scenes.test_triangle):

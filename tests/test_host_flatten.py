@@ -180,6 +180,11 @@ def test_errors_are_reported_not_panicked():
     inner = rt.ConstantMedium.new_with_color(rt.Sphere(rt.Point3(0, 0, 0), 1, m), 1.0, rt.Color(1, 1, 1))
     two = rt.ConstantMedium.new_with_color(inner, 1.0, rt.Color(1, 1, 1))  # a medium as the boundary of a medium: accepted
     rt.Scene(two, host_only=True).close()
+    img = rt.ImageTexture(np.zeros((2, 2, 3), dtype=np.uint8))  # a phase function that reads u,v: accepted, list frames cost 6 more stack entries
+    plain = rt.HittableList.with_object(rt.ConstantMedium.new_with_color(rt.Sphere(rt.Point3(0, 0, 0), 1, m), 1.0, rt.Color(1, 1, 1)))
+    stale = rt.HittableList.with_object(rt.ConstantMedium.new_with_texture(rt.Sphere(rt.Point3(0, 0, 0), 1, m), 1.0, img))
+    s_plain, s_stale = rt.Scene(plain, host_only=True), rt.Scene(stale, host_only=True)
+    assert s_stale.info().max_stack == s_plain.info().max_stack + 6
     with pytest.raises(rt.RtError) as e:  # three deep: the kernels resolve two levels
         rt.Scene(rt.ConstantMedium.new_with_color(two, 1.0, rt.Color(1, 1, 1)), host_only=True)
     assert e.value.code == F.RT_E_UNSUPPORTED
