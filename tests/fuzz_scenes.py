@@ -27,7 +27,11 @@ def rand_prim(g, m):
         return rt.Triangle(rt.Point3(*c), rt.Point3(*(c + g.uniform(-1.5, 1.5, 3))), rt.Point3(*(c + g.uniform(-1.5, 1.5, 3))), m)
     return rt.box_new(rt.Point3(*c), rt.Point3(*(c + g.uniform(0.2, 1.5, 3))), m)
 
-def rand_node(g, m, depth, allow_medium):
+RICH = {"on": False, "phase": None}  # rich media: any node as a boundary (a medium inside it included), phase functions over an image
+
+def rand_node(g, m, depth, allow_medium, media_level=0):
+    if RICH["on"]:
+        return rand_node_rich(g, m, depth, allow_medium, media_level)
     r = g.random()
     if depth >= 3 or r < 0.35:
         return rand_prim(g, m)
@@ -51,6 +55,36 @@ def rand_node(g, m, depth, allow_medium):
         return rt.ConstantMedium.new_with_color(b, float(g.uniform(0.05, 0.8)), rt.Color(1, 1, 1))
     return rand_prim(g, m)
 
+def rand_node_rich(g, m, depth, allow_medium, media_level):
+    r = g.random()
+    if depth >= 3 or r < 0.3:
+        return rand_prim(g, m)
+    if r < 0.55:
+        lst = rt.HittableList()
+        for _ in range(int(g.integers(1, 6))):
+            lst.add(rand_node_rich(g, m, depth + 1, allow_medium, media_level))
+        return lst
+    if r < 0.7:
+        lst = rt.HittableList()
+        for _ in range(int(g.integers(1, 12))):
+            lst.add(rand_node_rich(g, m, depth + 1, allow_medium and g.random() < 0.5, media_level))
+        return rt.BvhNode(lst)
+    if r < 0.8:
+        child = rand_node_rich(g, m, depth + 1, allow_medium, media_level)
+        if g.random() < 0.5:
+            return rt.Translate(child, rt.Vec3(*g.uniform(-2, 2, 3)))
+        return rt.RotateY(child, float(g.uniform(-90, 90)))
+    if allow_medium and media_level < 2:
+        if g.random() < 0.5:
+            b = rt.Sphere(rt.Point3(*g.uniform(-3, 3, 3)), float(g.uniform(0.8, 2.5)), m)
+        else:  # anything, a medium inside it included (constant_medium.rs:48-104 takes any Hittable)
+            b = rand_node_rich(g, m, depth + 1, True, media_level + 1)
+        dens = float(g.uniform(0.05, 0.8))
+        if RICH["phase"] is not None:
+            return rt.ConstantMedium.new_with_texture(b, dens, RICH["phase"])
+        return rt.ConstantMedium.new_with_color(b, dens, rt.Color(1, 1, 1))
+    return rand_prim(g, m)
+
 failures = []
 
 def describe(node, depth):
@@ -66,12 +100,17 @@ def describe(node, depth):
         c = getattr(node, attr, None)
         if c is not None: describe(c, depth + 1)
 
-def run(n_scenes, seed):
+def run(n_scenes, seed, rich_media=False):
     del failures[:]
     g = np.random.default_rng(seed)
     m = rt.Lambertian(rt.Color(.5, .5, .5))
     done = 0
+    RICH["on"] = rich_media
+    image = rt.ImageTexture(scenes.procedural_image(32, 16))
     for k in range(n_scenes):
+        # every other rich scene scatters with an image texture: its medium hits then report the u,v their record held
+        RICH["phase"] = image if (rich_media and k % 2 == 0) else None
+        uv = RICH["phase"] is not None
         world = rt.HittableList()
         for _ in range(int(g.integers(1, 8))):
             world.add(rand_node(g, m, 0, True))
@@ -85,12 +124,13 @@ def run(n_scenes, seed):
         for flags in (0, F.RT_HIT_ORDERED):
             for name, (ro, rd, rt_) in (("incoherent", (o, d, tm)), ("coherent", (oo, dd, None))):
                 try:
-                    compare(desc, ro, rd, time=rt_, min_hits=0, flags=flags)
+                    compare(desc, ro, rd, time=rt_, min_hits=0, flags=flags, medium_uv=uv)
                 except AssertionError as e:
                     print("MISMATCH scene", k, "flags", flags, name, str(e)[:400])
                     describe(world, 0)
                     failures.append(k)
         done += 1
+    RICH["on"] = False
     print("fuzz ok:" if not failures else "fuzz FAILED:", done, "scenes", "failures", failures)
     return done, list(failures)
 
@@ -98,7 +138,7 @@ def run(n_scenes, seed):
 def main():
     n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 30
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    done, failed = run(n_scenes, seed)
+    done, failed = run(n_scenes, seed, rich_media=len(sys.argv) > 3 and sys.argv[3] == "rich")
     sys.exit(1 if failed else 0)
 
 if __name__ == "__main__":

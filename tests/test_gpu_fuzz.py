@@ -12,6 +12,14 @@ def test_random_scene_graphs_match_the_oracle():
         assert done >= 70 and not failed, failed
 
 
+def test_random_scene_graphs_with_nested_and_textured_media():
+    """The same, with media whose boundary is any node (a medium inside it included) and, in every other scene, phase
+    functions over an image texture, whose medium hits must report the u,v the reference's record would hold."""
+    import fuzz_scenes
+    done, failed = fuzz_scenes.run(60, 11, rich_media=True)
+    assert done >= 40 and not failed, failed
+
+
 def test_random_scenes_render_like_the_oracle():
     """Random scene graphs with random materials (diffuse, checker, metal, glass, media), light lists of a quad and
     sometimes a sphere, random cameras: at most three pixels of a frame may differ from the oracle beyond rounding."""
