@@ -65,7 +65,7 @@ for k in KERNELS:
     fetch, write = c.get("FETCH_SIZE", 0.0) * 1024 * 2, c.get("WRITE_SIZE", 0.0) * 1024
     frame_bytes += fetch + write
     cyc = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0  # summed over the kernel's launches of the pass that carried it
-    valu = 4.0 * c.get("SQ_ACTIVE_INST_VALU", 0.0) / max(1.0, c.get("SQ_BUSY_CYCLES", 0.0) / 8.0 * 1024) if c.get("SQ_BUSY_CYCLES") else float("nan")
+    valu = 4.0 * c.get("SQ_ACTIVE_INST_VALU", 0.0) / (1024 * cyc) if cyc else float("nan")
     lane = c.get("SQ_THREAD_CYCLES_VALU", 0.0) / max(1.0, 64 * c.get("SQ_ACTIVE_INST_VALU", 0.0))
     wait = c.get("SQ_WAIT_ANY", 0.0) / max(1.0, c.get("SQ_WAVE_CYCLES", 0.0))
     hit = c.get("TCC_HIT_sum", 0.0) / max(1.0, c.get("TCC_REQ_sum", 0.0)) if c.get("TCC_REQ_sum") else float("nan")
@@ -74,7 +74,7 @@ for k in KERNELS:
 lines += ["",
           f"Frame: {frame_bytes / 1e9:.1f} GB through the fabric = {frame_bytes / rays:.0f} bytes per path-bounce; at the 8 TB/s HBM peak that is "
           f"{frame_bytes / 8e12 * 1e3:.1f} ms of the {all_ms:.1f} ms the kernels take, i.e. a memory roofline fraction of {frame_bytes / 8e12 * 1e3 / all_ms:.2f}.",
-          "VALU busy = 4 x SQ_ACTIVE_INST_VALU / (SQ_BUSY_CYCLES / 8 x 1024 SIMDs) (SQ_BUSY_CYCLES is summed over the 8 XCDs; SQ_ACTIVE_INST_VALU counts quad-cycles); lane utilisation = "
+          "VALU busy = 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x kernel cycles), kernel cycles = GRBM_GUI_ACTIVE / 8 summed over the kernel's launches (SQ_ACTIVE_INST_VALU counts quad-cycles); lane utilisation = "
           "SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); wave wait = SQ_WAIT_ANY / SQ_WAVE_CYCLES."]
 open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
