@@ -220,6 +220,12 @@ typedef struct rt_wide_node {
 /* Number of wide nodes (0 when the scene has no primitive-only BVH world); node 0 is the root. */
 int rt_scene_wide_node_count(const rt_scene* scene, uint64_t* count);
 int rt_scene_get_wide_nodes(const rt_scene* scene, uint64_t first, uint64_t count, rt_wide_node* out);
+/* The same tree in the packed form the primitive-BVH kernel reads for a triangle mesh (48-byte nodes, children
+ * addressed from two base indices, triangles in leaf order), decoded: child = RT_REF_NODE | packed index or
+ * RT_REF_TRI | index of the triangle in the description; box8 as above; box32 is zero.  `leaf_overlap`: sum of the
+ * triangles' box areas over the world box's (how many triangle boxes a random line crosses).  Count 0: no packed tree. */
+int rt_scene_packed_node_count(const rt_scene* scene, uint64_t* count, double* leaf_overlap);
+int rt_scene_get_packed_nodes(const rt_scene* scene, uint64_t first, uint64_t count, rt_wide_node* out);
 /* bounding_box() of an object of the description (hittable.rs:50), as 6 doubles. */
 int rt_scene_object_bounds(const rt_scene* scene, int32_t object, double out[6]);
 

@@ -1229,6 +1229,39 @@ int rt_scene_get_wide_nodes(const rt_scene* s, uint64_t first, uint64_t count, r
     return RT_OK;
 }
 
+int rt_scene_packed_node_count(const rt_scene* s, uint64_t* count, double* leaf_overlap) {
+    if (!s || !count) return set_err(RT_E_INVALID, "rt_scene_packed_node_count: null argument");
+    *count = s->flat.pnodes.size();
+    if (leaf_overlap) *leaf_overlap = s->flat.fast_leaf_overlap;
+    return RT_OK;
+}
+
+int rt_scene_get_packed_nodes(const rt_scene* s, uint64_t first, uint64_t count, rt_wide_node* out) {
+    if (!s || !out) return set_err(RT_E_INVALID, "rt_scene_get_packed_nodes: null argument");
+    if (first + count > s->flat.pnodes.size()) return set_err(RT_E_INVALID, "rt_scene_get_packed_nodes: range outside the node array");
+    for (uint64_t i = 0; i < count; ++i) {
+        const PNode& n = s->flat.pnodes[first + i];
+        rt_wide_node& o = out[i];
+        o.has_box8 = 1;
+        o._pad = 0;
+        const uint32_t n_inner = n.counts & 15u, n_all = n.counts >> 4;
+        for (uint32_t j = 0; j < 4; ++j) {
+            // the arithmetic of the kernel: slot j is node_base + j below n_inner, leaf_base + j from there on
+            uint32_t c = RT_REF_NONE;
+            if (j < n_inner) c = (RT_REF_NODE << 28) | RT_REF_INDEX(n.node_base + j);
+            else if (j < n_all) c = make_ref(RT_REF_TRI, s->flat.ptris[RT_REF_INDEX(n.leaf_base + j)].orig);
+            o.child[j] = c;
+            for (int a = 0; a < 3; ++a) {
+                const double step = std::ldexp(1.0, (int)n.exp[a] - 127);
+                o.box32[j][2 * a] = o.box32[j][2 * a + 1] = 0.0;
+                o.box8[j][2 * a] = (double)n.origin[a] + (double)n.qlo[a][j] * step;
+                o.box8[j][2 * a + 1] = (double)n.origin[a] + (double)n.qhi[a][j] * step;
+            }
+        }
+    }
+    return RT_OK;
+}
+
 int rt_scene_object_bounds(const rt_scene* s, int32_t object, double out[6]) {
     if (!s || !out) return set_err(RT_E_INVALID, "rt_scene_object_bounds: null argument");
     if (object < 0 || (size_t)object >= s->flat.object_bounds.size()) return set_err(RT_E_INVALID, "rt_scene_object_bounds: object id out of range");

@@ -281,6 +281,17 @@ class Scene:
         dt = np.dtype([("child", "<u4", 4), ("box32", "<f8", (4, 6)), ("box8", "<f8", (4, 6)), ("has_box8", "<i4"), ("_pad", "<i4")])
         return np.frombuffer(buf, dtype=dt, count=n).copy()
 
+    def packed_nodes(self):
+        """(nodes, leaf_overlap): the packed 48-byte tree the primitive-BVH kernel reads for a triangle mesh, decoded
+        like wide_nodes() (node 0 is the root; empty when the world is not one BVH over triangles)."""
+        cnt, overlap = C.c_uint64(), C.c_double()
+        F.check(F.lib.rt_scene_packed_node_count(self._h, C.byref(cnt), C.byref(overlap)))
+        n = cnt.value
+        buf = (F.rt_wide_node * max(1, n))()
+        F.check(F.lib.rt_scene_get_packed_nodes(self._h, 0, n, buf))
+        dt = np.dtype([("child", "<u4", 4), ("box32", "<f8", (4, 6)), ("box8", "<f8", (4, 6)), ("has_box8", "<i4"), ("_pad", "<i4")])
+        return np.frombuffer(buf, dtype=dt, count=n).copy(), overlap.value
+
     def object_bounds(self, obj: int) -> np.ndarray:
         out = (C.c_double * 6)()
         F.check(F.lib.rt_scene_object_bounds(self._h, obj, out))

@@ -163,6 +163,48 @@ def test_resolve_equals_oracle_and_ppm(tmp_path):
     assert lines[3] == " ".join(str(int(v)) for v in img.rgb[0, 0])
 
 
+def test_packed_tree_is_the_wide_tree_relaid():
+    """The 48-byte nodes of a triangle mesh (children addressed from two base indices, inner children first, triangles
+    in leaf order) describe the same tree as the 64-byte nodes they are made from: walked side by side from the roots,
+    every node has the same children with the same 8-bit boxes, and every triangle of the mesh is a leaf exactly once."""
+    m = rt.Lambertian(rt.Color(.5, .5, .5))
+    n_tris = 3001
+    s = rt.Scene(rt.Mesh(scenes.triangle_soup(n_tris, seed=17, edge=0.06), m), host_only=True)
+    wide = s.wide_nodes()
+    packed, overlap = s.packed_nodes()
+    assert len(packed) > n_tris // 4 and wide[0]["has_box8"] == 1
+    assert len(packed) < len(wide)  # dense: the 64-byte array is indexed like the binary tree
+    seen = np.zeros(n_tris, dtype=int)
+    todo = [(0, 0)]
+    kind = lambda r: int(r) >> 28
+    while todo:
+        w, p = todo.pop()
+        wc = {tuple(wide[w]["box8"][j]): int(wide[w]["child"][j]) for j in range(4) if wide[w]["child"][j] != F.RT_REF_NONE}
+        pc = [(tuple(packed[p]["box8"][j]), int(packed[p]["child"][j])) for j in range(4) if packed[p]["child"][j] != F.RT_REF_NONE]
+        assert len(wc) == len(pc), (w, p)
+        kinds = [kind(r) for _, r in pc]
+        assert kinds == sorted(kinds, key=lambda k: k != F.RT_REF_NODE)  # inner children first
+        for box, ref in pc:
+            assert box in wc, (w, p, box)
+            if kind(ref) == F.RT_REF_NODE:
+                assert kind(wc[box]) == F.RT_REF_NODE
+                todo.append((wc[box] & 0x0FFFFFFF, ref & 0x0FFFFFFF))
+            else:
+                assert ref == wc[box] and kind(ref) == F.RT_REF_TRI
+                seen[ref & 0x0FFFFFFF] += 1
+    assert (seen == 1).all()
+    # boxes a random line through the world box crosses: sum of triangle box areas / world box area
+    tri = scenes.triangle_soup(n_tris, seed=17, edge=0.06)
+    ext = tri.max(axis=1) - tri.min(axis=1)
+    area = lambda e: e[..., 0] * e[..., 1] + e[..., 1] * e[..., 2] + e[..., 2] * e[..., 0]
+    wb = np.array(s.info().world_bounds[:]).reshape(3, 2)
+    assert abs(overlap - area(ext).sum() / area(wb[:, 1] - wb[:, 0])) < 0.05 * overlap
+    lst = rt.HittableList()
+    lst.add(rt.Sphere(rt.Point3(0, 0, 0), 1.0, m))
+    lst.add(rt.Triangle(rt.Point3(0, 0, 2), rt.Point3(1, 0, 2), rt.Point3(0, 1, 2), m))
+    assert len(rt.Scene(rt.BvhNode(lst), host_only=True).packed_nodes()[0]) == 0  # not all triangles: no packed tree
+
+
 def test_errors_are_reported_not_panicked():
     m = rt.Lambertian(rt.Color(.5, .5, .5))
     with pytest.raises(rt.RtError) as e:  # bvh.rs:17 indexes an empty vector
