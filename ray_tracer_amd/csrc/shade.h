@@ -140,23 +140,21 @@ RT_DEV double lights_pdf_value(const DScene& S, D3 origin, D3 direction) {
 // an orthonormal basis about an axis, draw two numbers, and place a point at azimuth 2*pi*r1.  Lanes of either kind
 // run that part together (`SAMPLE_LOBE`), each with its own axis and its own two radial expressions; a quad light
 // (quad.rs:133-136) or a list member without a sampler (hittable.rs:54-56) yields its direction at once.
-enum { SAMPLE_DONE = 0, SAMPLE_LOBE = 1 };
+// All three take exactly two draws, r1 then r2 (quad.rs:133-136, sphere.rs:57-67, the cosine direction of pdf.rs:57-59), so
+// the lanes of a wave make them together whichever sampler each of them needs, and only the few operations that turn
+// (r1, r2) into a direction differ.
+enum { SAMPLE_DONE = 0, SAMPLE_LOBE = 1, SAMPLE_QUAD = 2 };
 struct LobeSample {
     D3 axis;       // the normal, or the direction to the sphere's centre
     double cone;   // sphere light: sqrt(1 - r^2 / distance^2) - 1; unused for the cosine lobe
     bool sphere;
+    uint32_t quad; // SAMPLE_QUAD: the quad light to sample
 };
 
 RT_DEV int light_pick_one(const DScene& S, DLight l, D3 origin, Rng& g, D3& dir, LobeSample& lobe) { // `l` is wave-uniform
     if (l.kind == RT_REF_QUAD) {
-        const DQuad q = uniform_load(S.quads + l.index);
-        double r1 = g.next();
-        D3 a = r1 * d3p(q.u);
-        double r2 = g.next();
-        D3 b = r2 * d3p(q.v);
-        D3 p = d3p(q.q) + a + b;
-        dir = p - origin;
-        return SAMPLE_DONE;
+        lobe.quad = l.index;
+        return SAMPLE_QUAD;
     }
     if (l.kind == RT_REF_SPHERE) {
         const DSphere s = uniform_load(S.spheres + l.index);
@@ -187,10 +185,28 @@ RT_DEV int lights_pick(const DScene& S, D3 origin, Rng& g, D3& dir, LobeSample& 
     return mode;
 }
 
-RT_DEV D3 sample_lobe(const LobeSample& lobe, Rng& g) {
+// Quad::random (quad.rs:133-136): q + r1 * u + r2 * v - origin.  Lanes may have picked different quads: each distinct
+// one is read once, as a wave-uniform record.
+RT_DEV D3 sample_quad(const DScene& S, uint32_t quad, bool mine, D3 origin, double r1, double r2) {
+    D3 dir = d3(1.0, 0.0, 0.0);
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(mine);
+    while (todo) {
+        const uint32_t qi = (uint32_t)__builtin_amdgcn_readlane((int)quad, __builtin_ctzll(todo));
+        const DQuad q = uniform_load(S.quads + qi);
+        const bool here = mine && quad == qi;
+        if (here) {
+            D3 a = r1 * d3p(q.u);
+            D3 b = r2 * d3p(q.v);
+            D3 p = d3p(q.q) + a + b;
+            dir = p - origin;
+        }
+        todo &= ~__builtin_amdgcn_ballot_w64(here);
+    }
+    return dir;
+}
+
+RT_DEV D3 sample_lobe(const LobeSample& lobe, double r1, double r2) {
     Onb uvw(lobe.axis);
-    double r1 = g.next();
-    double r2 = g.next();
     double sphi, cphi;
     sincos_2pi(r1, sphi, cphi);
     // sphere.rs:62-66: z = 1 + r2*(sqrt(1 - r^2/d^2) - 1), x = cos(phi)*sqrt(1 - z*z); pdf.rs / vec3 random_cosine_direction:
@@ -252,11 +268,16 @@ RT_DEV bool shade_hit(const DScene& S, const HitRec& h, D3 ray_dir, Rng& g, D3& 
     if (S.n_lights >= 0) from_light = g.next() < 0.5; // MixturePdf::generate (pdf.rs:119-125)
     int mode = SAMPLE_DONE;
     LobeSample lobe;
-    lobe.axis = h.normal; lobe.cone = 0.0; lobe.sphere = false;
+    lobe.axis = h.normal; lobe.cone = 0.0; lobe.sphere = false; lobe.quad = 0u;
     if (from_light) mode = lights_pick(S, h.p, g, dir, lobe);
     else if (lambert) mode = SAMPLE_LOBE;                              // pdf.rs:57-59
     else dir = random_unit_vector(g);                                  // pdf.rs:36-38
-    if (mode == SAMPLE_LOBE) dir = sample_lobe(lobe, g);
+    if (mode != SAMPLE_DONE) {
+        const double r1 = g.next();
+        const double r2 = g.next();
+        const D3 towards_quad = sample_quad(S, lobe.quad, mode == SAMPLE_QUAD, h.p, r1, r2);
+        dir = mode == SAMPLE_QUAD ? towards_quad : sample_lobe(lobe, r1, r2);
+    }
     double mat_pdf;
     if (lambert) { // CosinePdf::value (pdf.rs:52-55)
         double cosine_theta = dot(unit_vector(dir), unit_normal);

@@ -149,6 +149,26 @@ def test_phase_function_over_an_image_texture():
         assert_same_ray_count(ctr.render_rays, stats["rays"])
 
 
+def _two_quad_lights():
+    """The Cornell box with a second quad light on the left wall, named in the light list between the ceiling light
+    and the glass sphere: lanes of one wave sample different quads."""
+    world, lights, cam = scenes.cornell_box()
+    world.add(rt.Quad(rt.Point3(554.0, 200.0, 200.0), rt.Vec3(0.0, 0.0, 150.0), rt.Vec3(0.0, 150.0, 0.0), rt.DiffuseLight.from_color(rt.Color(4.0, 6.0, 9.0))))
+    members = list(lights.objects)
+    lights = rt.HittableList()
+    lights.add(members[0])
+    lights.add(rt.Quad(rt.Point3(554.0, 200.0, 200.0), rt.Vec3(0.0, 0.0, 150.0), rt.Vec3(0.0, 150.0, 0.0), rt.Lambertian(rt.Color(0, 0, 0))))
+    for m in members[1:]:
+        lights.add(m)
+    return world, lights, cam
+
+
+def test_light_list_with_two_quads_and_a_sphere():
+    cam, c, a, b, stats, ctr, gpu = render_both(_two_quad_lights, 48, 16, 30, seed=14)
+    check(c, a, b)
+    assert_same_ray_count(ctr.render_rays, stats["rays"])
+
+
 def test_texture_scenes():
     for build in (scenes.checkered_spheres, scenes.earth, scenes.perlin_spheres, scenes.simple_light, scenes.quads,
                   scenes.for_output13, scenes.test_triangle):
