@@ -168,6 +168,7 @@ __shared__ uint32_t s_lane_iters[256]; // loop iterations of each lane's current
 // and copies it out on every hit (hittable_list.rs:46-57); BvhNode, Translate and RotateY hand their caller's record
 // down.  Only a phase function over an image texture reads these values, so only scenes that have one pay for the
 // book-keeping (UV = true): the record of the current frame is named by the primitive hit that last wrote it.
+constexpr uint32_t UV_UNWRITTEN = 0xFFFFFFFEu; // stands in for Best::ref during a step: no primitive accepted a hit yet
 struct UvTrack {
     uint32_t ref;  // RT_REF_NONE: the default record, u = v = 0
     int32_t ctx;
@@ -195,9 +196,12 @@ __device__ __forceinline__ void traverse(const DScene& S, uint32_t root, RayD ra
         const uint32_t kind = cur >> 28, idx = cur & 0x0FFFFFFFu;
         bool pop = true;
         bool wide_done = false;
-        const double uv_t0 = best.t;          // (UV) the record before this step: a primitive that changes it becomes the
-        const uint32_t uv_ref0 = best.ref;    // source of the frame's u,v
-        const int32_t uv_ctx0 = best.ctx;
+        // (UV) a primitive that accepts a hit in this step writes the whole record and so becomes the source of the
+        // frame's u,v -- also when it writes the values the record already holds (the same primitive accepted again at
+        // the same t through a second frame, e.g. the duplicated child of a one-object span, bvh.rs:41-44), which a
+        // comparison of the record before and after would miss: the step starts from a reference no test writes
+        const uint32_t uv_ref0 = best.ref;
+        if (UV && kind != RT_REF_MEDIUM && kind != REF_LISTEND) best.ref = UV_UNWRITTEN;
         if (ORDERED && kind == RT_REF_NODE) {
             RT_STEP_BEGIN();
             WNodeLoad wn;
@@ -453,8 +457,9 @@ __device__ __forceinline__ void traverse(const DScene& S, uint32_t root, RayD ra
                 }
             }
         }
-        if (UV && kind != RT_REF_MEDIUM && kind != REF_LISTEND && (best.t != uv_t0 || best.ref != uv_ref0 || best.ctx != uv_ctx0)) {
-            uvt->ref = best.ref; uvt->ctx = best.ctx; uvt->t = best.t; uvt->any = true; // a primitive wrote the whole record
+        if (UV && kind != RT_REF_MEDIUM && kind != REF_LISTEND) {
+            if (best.ref != UV_UNWRITTEN) { uvt->ref = best.ref; uvt->ctx = best.ctx; uvt->t = best.t; uvt->any = true; }
+            else best.ref = uv_ref0;
         }
         if (pop) {
             RT_STEP_BEGIN();

@@ -130,6 +130,7 @@ def run(n_scenes, seed, rich_media=False):
                     describe(world, 0)
                     failures.append(k)
         done += 1
+        if done % 100 == 0: print("...", done, "scenes compared,", len(failures), "mismatches", flush=True)
     RICH["on"] = False
     print("fuzz ok:" if not failures else "fuzz FAILED:", done, "scenes", "failures", failures)
     return done, list(failures)

@@ -234,6 +234,21 @@ def test_medium_hits_report_the_u_v_their_record_held():
     w3.add(fog(shell, 0.7))
     compare(rt.SceneDesc.from_world(w3), o, d, time=tm, seed=5, min_hits=1000, flags=F.RT_HIT_ORDERED, medium_uv=True)
 
+    # (4) a one-object span stores its object as both children (bvh.rs:41-44), so the list below is walked twice, each
+    #     time with a fresh temp_rec: the second time the quad is accepted again at the t the record already holds and
+    #     the medium draws again -- a medium hit of the second walk reports the quad's u,v
+    dup = rt.HittableList()
+    dup.add(rt.Quad(rt.Point3(-3, -3, 1.5), rt.Vec3(6, 0, 0), rt.Vec3(0, 6, 0), m))
+    dup.add(fog(rt.Sphere(rt.Point3(0, 0, 0), 1.4, m), 0.5))
+    one = rt.HittableList()
+    one.add(dup)
+    w4 = rt.HittableList()
+    w4.add(rt.BvhNode(one))
+    for flags in (0, F.RT_HIT_ORDERED):
+        a, b = compare(rt.SceneDesc.from_world(w4), o, d, time=tm, seed=6, min_hits=3000, flags=flags, medium_uv=True)
+    med = (b["prim"] >> 28) == F.RT_REF_MEDIUM
+    assert med.sum() > 500 and (b["u"][med] != 0).sum() > 100
+
 
 def test_cornell_smoke_media_inside_bvh():
     world, lights, cam = scenes.cornell_smoke()
