@@ -203,7 +203,23 @@ __global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, 
                 }
                 if (!active) {
                     const unsigned long long qi = wave_next + (unsigned long long)__builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u)); // idle lanes below this one
-                    if (PREP) {
+                    if (PREP && PACKED) {
+                        if (qi < wave_end) {
+                            const PRayC p = reinterpret_cast<const PRayC*>(prep)[qi]; // half a line, four 16-byte loads
+                            r.ox = p.o[0]; r.oy = p.o[1]; r.oz = p.o[2];
+                            r.dx = p.d[0]; r.dy = p.d[1]; r.dz = p.d[2];
+                            ray32_from_inv(r, p.inv, scene_extent, q);
+                            best_t = (opt & 4u) ? rays.tmax[p.idx] : D_INF;
+                            best32 = f32_round_up(best_t);
+                            best_ref = RT_REF_NONE;
+                            pend = RT_REF_NONE;
+                            if (SLOT_IN_LDS) s_slot[threadIdx.x] = p.idx; else ray_slot = (slot_t)p.idx;
+                            cur = root;
+                            RT_STACK_RESET(st);
+                            active = true;
+                            pop = false;
+                        }
+                    } else if (PREP) {
                         if (qi < wave_end) {
                             const PRay p = prep[qi]; // one line, eight 16-byte loads
                             r.ox = p.o[0]; r.oy = p.o[1]; r.oz = p.o[2];

@@ -907,7 +907,9 @@ int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit
             const int cblocks = (int)std::min<uint64_t>(2048, (n + REORDER_BLOCK - 1) / REORDER_BLOCK);
             hipLaunchKernelGGL(reorder_count_kernel, dim3(cblocks), dim3(REORDER_BLOCK), 0, st, *rays, (unsigned long long)n, s->grid, s->prep_bins, s->prep_hist);
             hipLaunchKernelGGL(reorder_scan_kernel, dim3(1), dim3(1024), 0, st, s->prep_hist, s->prep_cursor);
-            hipLaunchKernelGGL(reorder_scatter_kernel, dim3((unsigned)((n + REORDER_TILE - 1) / REORDER_TILE)), dim3(SCATTER_BLOCK), 0, st, *rays,
+            // (the packed tree takes 64-byte records; it is not used when the batch brings lower ends of its own, see below)
+            hipLaunchKernelGGL((s->fast_fmt == NODES_PACKED && !(opt & 2u)) ? reorder_scatter_kernel<true> : reorder_scatter_kernel<false>,
+                               dim3((unsigned)((n + REORDER_TILE - 1) / REORDER_TILE)), dim3(SCATTER_BLOCK), 0, st, *rays,
                                (unsigned long long)n, opt, 0.001, s->fast_extent, (const uint16_t*)s->prep_bins, s->prep_cursor, s->prep);
             HIP_TRY(hipGetLastError());
         }

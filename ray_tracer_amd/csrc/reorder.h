@@ -35,6 +35,32 @@ struct alignas(128) PRay {      // one line: everything the kernel needs to star
 };
 static_assert(sizeof(PRay) == 128, "a prepared ray is one cache line");
 
+// The packed tree (triangles only, default lower end of the interval) needs less: origin, direction, 1/d and the
+// ray's index, half a line.  The kernel derives the offset terms of the slab test from 1/d when it starts the ray
+// (ray32_from_inv), and reads an upper end of the interval, if the caller gave one, from the caller's batch.
+struct alignas(64) PRayC {
+    double o[3], d[3];
+    float inv[3];               // (float)(1 / d)
+    uint32_t idx;
+};
+static_assert(sizeof(PRayC) == 64, "a compact prepared ray is half a cache line");
+
+// Ray32 from the f32 inverse alone: c = -(o * inv32) rounded to f32.  Both terms of t = b * inv32 + c then carry
+// the same rounding of the inverse, a relative error of 2^-24 in t, i.e. at most 2^-24 * |inv| * (|b| + |o|) more
+// than the form make_ray32 builds; the margin is widened by a quarter (10 instead of 8 units of 2^-24) to cover it.
+RT_DEV void ray32_from_inv(const RayD& r, const float inv32[3], float scene_extent, Ray32& q) {
+    const double o[3] = {r.ox, r.oy, r.oz}, d[3] = {r.dx, r.dy, r.dz};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float c = (float)(-(o[k] * (double)inv32[k]));
+        const float e = 5.9604644775390625e-07f * fabsf(inv32[k]) * (scene_extent + fabsf((float)o[k])); // 1.25 * 2^-21
+        q.inv[k] = inv32[k];
+        q.cn[k] = c - e;
+        q.cf[k] = c + e;
+        q.neg[k] = d[k] < 0.0;
+    }
+}
+
 struct ReorderGrid {            // cell = clamp((o - lo) * scale, 0, 15) per axis
     double lo[3];
     double scale[3];
@@ -99,9 +125,12 @@ __global__ __launch_bounds__(1024) void reorder_scan_kernel(uint32_t* hist, uint
 // eight 16-byte stores into a line no other lane of the instruction touches, and each of them went to memory as a
 // transaction of its own (2^24 records took 1.1 ms, the time of eight times their bytes).  So the wave stages its 64
 // records in LDS and stores them with eight lanes per record: every store instruction writes eight complete lines.
+// COMPACT: 64-byte records (PRayC), four lanes per record.
+template <bool COMPACT>
 __global__ __launch_bounds__(SCATTER_BLOCK) void reorder_scatter_kernel(rt_ray_batch rays, unsigned long long n, uint32_t opt, double tmin_default,
                                                                           float scene_extent, const uint16_t* bins, uint32_t* cursor, PRay* out) {
-    constexpr int WAVES = SCATTER_BLOCK / 64, PER = REORDER_TILE / SCATTER_BLOCK, STRIDE = 9; // 9 x 16 bytes per staged record: conflict-free
+    constexpr int PIECES = COMPACT ? 4 : 8;                                                   // 16-byte pieces per record
+    constexpr int WAVES = SCATTER_BLOCK / 64, PER = REORDER_TILE / SCATTER_BLOCK, STRIDE = PIECES + 1; // odd number of 16-byte pieces per staged record: conflict-free
     __shared__ uint32_t s_count[REORDER_BINS];
     __shared__ uint32_t s_base[REORDER_BINS];
     __shared__ uint4 s_stage[WAVES * 64 * STRIDE];
@@ -134,34 +163,45 @@ __global__ __launch_bounds__(SCATTER_BLOCK) void reorder_scatter_kernel(rt_ray_b
             r.ox = rays.ox[i]; r.oy = rays.oy[i]; r.oz = rays.oz[i];
             r.dx = rays.dx[i]; r.dy = rays.dy[i]; r.dz = rays.dz[i];
             set_inverse(r);
-            Ray32 q;
-            make_ray32(r, scene_extent, q);
-            PRay p;
-            p.o[0] = r.ox; p.o[1] = r.oy; p.o[2] = r.oz;
-            p.d[0] = r.dx; p.d[1] = r.dy; p.d[2] = r.dz;
-            p.time = (opt & 1u) ? rays.time[i] : 0.0;
-            p.tmin = (opt & 2u) ? rays.tmin[i] : tmin_default;
-            p.tmax = (opt & 4u) ? rays.tmax[i] : D_INF;
+            if (COMPACT) {
+                PRayC p;
+                p.o[0] = r.ox; p.o[1] = r.oy; p.o[2] = r.oz;
+                p.d[0] = r.dx; p.d[1] = r.dy; p.d[2] = r.dz;
+                p.inv[0] = (float)r.ix; p.inv[1] = (float)r.iy; p.inv[2] = (float)r.iz;
+                p.idx = (uint32_t)i;
+                const uint4* src = reinterpret_cast<const uint4*>(&p);
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { p.inv[k] = q.inv[k]; p.cn[k] = q.cn[k]; p.cf[k] = q.cf[k]; }
-            p.idx = (uint32_t)i;
-            p.neg = (q.neg[0] ? 1u : 0u) | (q.neg[1] ? 2u : 0u) | (q.neg[2] ? 4u : 0u);
-            p.tmin32 = f32_round_down(p.tmin);
-            p.tmax32 = f32_round_up(p.tmax);
-            p._pad = 0u;
-            const uint4* src = reinterpret_cast<const uint4*>(&p);
+                for (int k = 0; k < PIECES; ++k) stage[lane * STRIDE + k] = src[k];
+            } else {
+                Ray32 q;
+                make_ray32(r, scene_extent, q);
+                PRay p;
+                p.o[0] = r.ox; p.o[1] = r.oy; p.o[2] = r.oz;
+                p.d[0] = r.dx; p.d[1] = r.dy; p.d[2] = r.dz;
+                p.time = (opt & 1u) ? rays.time[i] : 0.0;
+                p.tmin = (opt & 2u) ? rays.tmin[i] : tmin_default;
+                p.tmax = (opt & 4u) ? rays.tmax[i] : D_INF;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) stage[lane * STRIDE + k] = src[k];
+                for (int k = 0; k < 3; ++k) { p.inv[k] = q.inv[k]; p.cn[k] = q.cn[k]; p.cf[k] = q.cf[k]; }
+                p.idx = (uint32_t)i;
+                p.neg = (q.neg[0] ? 1u : 0u) | (q.neg[1] ? 2u : 0u) | (q.neg[2] ? 4u : 0u);
+                p.tmin32 = f32_round_down(p.tmin);
+                p.tmax32 = f32_round_up(p.tmax);
+                p._pad = 0u;
+                const uint4* src = reinterpret_cast<const uint4*>(&p);
+#pragma unroll
+                for (int k = 0; k < PIECES; ++k) stage[lane * STRIDE + k] = src[k];
+            }
         }
         spos[lane] = pos;
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const uint32_t rec = (uint32_t)k * 8u + (lane >> 3), piece = lane & 7u;
+        for (int k = 0; k < PIECES; ++k) { // 64 / PIECES records per store instruction, PIECES lanes each
+            const uint32_t rec = (uint32_t)k * (64u / PIECES) + lane / PIECES, piece = lane % PIECES;
             const uint32_t rpos = spos[rec];
             const uint4 v = stage[rec * STRIDE + piece];
-            if (rpos != 0xFFFFFFFFu) reinterpret_cast<uint4*>(out + rpos)[piece] = v;
+            if (rpos != 0xFFFFFFFFu) reinterpret_cast<uint4*>(out)[(size_t)rpos * PIECES + piece] = v;
         }
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
