@@ -1,6 +1,7 @@
 #!/bin/bash
 # A/B of library builds in one call on one box: traversal time of the two bench batches (soup, closed mesh) for every
-# library under ray_tracer_amd/variants/, twice over, alternating.  Extra environment is passed through.
+# library under ray_tracer_amd/variants/, twice over, alternating.  Extra environment is passed through; AB_ENV holds
+# settings that are applied to the libraries whose name contains AB_MATCH only.
 cd "$GRAFT_REPO_ROOT" || exit 1
 for round in 1 2; do for lib in ray_tracer_amd/variants/*.so; do for scene in soup mesh; do
   echo -n "$(basename $lib) $scene: "

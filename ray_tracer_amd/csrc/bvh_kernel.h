@@ -116,8 +116,10 @@ RT_DEV float ubyte_f32(uint32_t w, int byte) { return (float)((w >> (8 * byte)) 
 // (RS = doubles per record; out_t shares that stride, out_prim counts 32-bit words: 2 * RS).
 // PREP: the batch is the array `prep` of prepared records in bin order (reorder.h) instead of `rays`; a record
 // carries the ray's index in the caller's batch, where the result goes.
+// Launch bound: the packed variant on prepared rays is held to 80 vector registers (it needs 81 unbounded), which
+// lets a sixth wave per SIMD in without spilling; the other variants would spill and stay as they compile.
 template <int PRIM, bool COUNT, int FMT, int RS, bool PREP>
-__global__ __launch_bounds__(FAST_BLOCK) void bvh4_closest_hit_kernel(DScene S, uint32_t root, rt_ray_batch rays,
+__global__ __launch_bounds__(FAST_BLOCK, (FMT == NODES_PACKED && PREP && !COUNT) ? 6 : 1) void bvh4_closest_hit_kernel(DScene S, uint32_t root, rt_ray_batch rays,
                                                                        unsigned long long n_in, RayQueue rq, uint32_t opt, double tmin_default,
                                                                        float scene_extent, double* out_t, uint32_t* out_prim,
                                                                        unsigned long long* work_counter,

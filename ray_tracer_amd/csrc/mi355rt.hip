@@ -594,6 +594,7 @@ struct rt_scene {
     rt_counters counters{};
     int grid_blocks = 0;
     int fast_grid_blocks = 0;
+    int fast_grid_blocks_prep = 0; // the same for launches on prepared rays (reorder.h), whose kernel variant fits more waves
     int extend_blocks = 0, shade_blocks = 0, tail_blocks = 0;
     size_t fast_lds = 0;
     uint2* fast_spill = nullptr; // HBM overflow of the per-lane stacks: [entry][thread]
@@ -742,17 +743,25 @@ int pick_grid(rt_scene* s) {
         if (s->tune.debug)
             fprintf(stderr, "[mi355rt] primitive-BVH kernel: node format=%d (inflation %.3f, leaf overlap %.2f) blocks/CU=%d\n", s->fast_fmt, s->flat.quant_inflation,
                     s->flat.fast_leaf_overlap, fast_per_cu);
-        // Workgroups per CU.  The packed kernel fits six (81 registers), and more waves hide more latency, but they
-        // also share the CU's vector L1 and the XCD's L2: measured on 2^24 reordered rays, 4 / 5 / 6 workgroups take
-        // 7.56 / 7.06 / 7.04 ms on the 2^20-triangle soup and 3.52 / 3.68 / 3.88 ms on a closed surface of 1.3 M
-        // triangles, whose rays of one cell walk the same few nodes.  Five, or four where rays cross few triangle boxes.
+        // Workgroups per CU.  More waves hide more latency, but they also share the CU's vector L1 and the XCD's L2:
+        // measured on 2^24 reordered rays, 4 / 5 workgroups take 7.56 / 7.06 ms on the 2^20-triangle soup and
+        // 3.52 / 3.68 ms on a closed surface of 1.3 M triangles, whose rays of one cell walk the same few nodes.  Five
+        // (the kernel has 81 registers), or four where rays cross few triangle boxes.
         if (s->fast_fmt == NODES_PACKED) fast_per_cu = std::min(fast_per_cu, s->flat.fast_leaf_overlap > POSTPONE_MIN_OVERLAP ? 5 : 4);
         else fast_per_cu = std::min(fast_per_cu, 5);
         if (s->tune.fast_blocks_per_cu > 0) fast_per_cu = std::min(fast_per_cu, s->tune.fast_blocks_per_cu);
         s->fast_grid_blocks = prop.multiProcessorCount * std::max(1, fast_per_cu);
+        // The variant that reads prepared rays is built to 80 registers, six waves per SIMD (bvh_kernel.h: no spills;
+        // the soup's traversal 6.72 -> 6.49 ms; 72 registers for seven waves spill ten and take 7.7 ms).
+        int prep_per_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&prep_per_cu, fast_kernel_prepared(s->fast_prim, false, s->fast_fmt), FAST_BLOCK, 0));
+        if (s->fast_fmt == NODES_PACKED) prep_per_cu = std::min(prep_per_cu, s->flat.fast_leaf_overlap > POSTPONE_MIN_OVERLAP ? 6 : 4);
+        else prep_per_cu = std::min(prep_per_cu, 5);
+        if (s->tune.fast_blocks_per_cu > 0) prep_per_cu = std::min(prep_per_cu, s->tune.fast_blocks_per_cu);
+        s->fast_grid_blocks_prep = prop.multiProcessorCount * std::max(1, prep_per_cu);
         {
             size_t entries = (size_t)std::max<uint32_t>(s->flat.fast_stack, 1u);
-            size_t bytes = entries * (size_t)s->fast_grid_blocks * FAST_BLOCK * sizeof(uint2);
+            size_t bytes = entries * (size_t)std::max(s->fast_grid_blocks, s->fast_grid_blocks_prep) * FAST_BLOCK * sizeof(uint2);
             void* p = nullptr;
             HIP_TRY(hipMalloc(&p, bytes));
             s->allocs.push_back(p);
@@ -901,6 +910,7 @@ int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit
         // large batches are binned by origin cell and prepared first (reorder.h); the allocation-free entry point
         // (ctx_scratch given) never grows the pass's scratch and so goes without it
         const bool reorder = tn.reorder && !ctx_scratch && n >= tn.reorder_min && n <= 0xFFFFFFFFull;
+        if (reorder) fblocks = (int)std::min<uint64_t>((uint64_t)s->fast_grid_blocks_prep, (waves + (FAST_BLOCK / 64) - 1) / (FAST_BLOCK / 64));
         if (reorder) {
             int rc = ensure_reorder_scratch(s, n);
             if (rc) return rc;
