@@ -217,8 +217,8 @@ def _roofline(args, n, dev_ms, box_tests, prim_tests, cpu, o, d, tm, np):
          "count_sample_rays": m}
     if ordered:
         # what the kernel's own record formats ask for: 48-byte packed nodes, 80 bytes of a triangle's line (vertices and
-        # index), the 128-byte prepared ray, 12 bytes of (t, primitive) out
-        r["requested_bytes_per_ray"] = 48 * node_visits + 80 * prim_tests + 128 + 12
+        # index), the 64-byte prepared ray, 12 bytes of (t, primitive) out
+        r["requested_bytes_per_ray"] = 48 * node_visits + 80 * prim_tests + 64 + 12
         r["requested_gbs"] = r["requested_bytes_per_ray"] * n / (kernel_ms * 1e-3) / 1e9
     prof = _profile_for_this_build()
     if prof:
