@@ -414,6 +414,29 @@ def test_packed_and_64_byte_nodes_agree(monkeypatch):
     packed.close(); plain.close()
 
 
+def test_prepared_rays_of_the_packed_tree(monkeypatch):
+    """Batches of 2^18 rays or more are binned by origin cell and handed to the packed kernel as 64-byte prepared
+    records (origin, direction, f32 inverse, index); the kernel derives the offsets of its conservative slab test from
+    the inverse.  With the threshold lowered the same path takes small batches: axis-parallel rays and a zero
+    direction (the inverse is infinite, 0 * inf in the offsets), origins on box planes, ragged sizes, an upper end
+    of the interval read from the caller's array -- all against the oracle."""
+    m = rt.Lambertian(rt.Color(.5, .5, .5))
+    desc = rt.SceneDesc.from_world(rt.Mesh(scenes.triangle_soup(6000, seed=51, edge=0.07), m))
+    monkeypatch.setenv("MI355RT_REORDER_MIN", "1")
+    o, d = _edge_rays([0, 1, 0, 1, 0, 1])
+    compare(desc, o, d, min_hits=300, flags=F.RT_HIT_ORDERED)
+    oo, dd, tm = scenes.incoherent_rays(30000, [-0.2, 1.2, -0.2, 1.2, -0.2, 1.2], seed=52)
+    compare(desc, oo, dd, time=tm, min_hits=5000, flags=F.RT_HIT_ORDERED)
+    tmax = np.random.default_rng(8).uniform(0.02, 1.0, len(oo))
+    compare(desc, oo, dd, tmax=tmax, min_hits=2000, flags=F.RT_HIT_ORDERED)
+    for n in (1, 63, 65, 1000):
+        compare(desc, oo[:n], dd[:n], min_hits=0, flags=F.RT_HIT_ORDERED)
+    scene = rt.Scene(desc)
+    scene.closest_hit(oo, dd, flags=F.RT_HIT_ORDERED)
+    assert scene.counters().ms_last_reorder > 0.0  # the batch did go through the reorder pass
+    scene.close()
+
+
 def test_deep_stacks_of_instanced_nested_lists():
     """A BVH over Translate(RotateY(nested lists)) leaves: the ordered traversal keeps deferred siblings, restore
     entries and list continuations on the LDS stack at the same time (up to 23 entries with 4-wide nodes here, 27
