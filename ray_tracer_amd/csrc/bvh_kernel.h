@@ -284,7 +284,8 @@ __global__ __launch_bounds__(FAST_BLOCK, (FMT == NODES_PACKED && PREP && !COUNT)
                 if (QUANT) {
                     uint4 h0, qa, qb;
                     if (PACKED) {
-                        const uint4* row = reinterpret_cast<const uint4*>(qbase + (size_t)(cur & 0x0FFFFFFFu) * sizeof(PNode));
+                        // (a 32-bit byte offset from a base in scalar registers: the packed arrays stay below 4 GB, flatten.cpp)
+                        const uint4* row = reinterpret_cast<const uint4*>(qbase + (uint32_t)((cur & 0x0FFFFFFFu) * (uint32_t)sizeof(PNode)));
                         h0 = row[0];                 // origin x y z | exp x, exp y, exp z, child counts
                         qa = row[1];                 // qlo x | qlo y | qlo z | qhi x   (one byte per child)
                         qb = row[2];                 // qhi y | qhi z | first inner child | first triangle - inner children
@@ -419,7 +420,7 @@ __global__ __launch_bounds__(FAST_BLOCK, (FMT == NODES_PACKED && PREP && !COUNT)
                 if (has_pend && quorum) {
                     const uint32_t kind = pend >> 28, idx = pend & 0x0FFFFFFFu;
                     if (PACKED) {
-                        const PTri* tp = S.ptris + idx;
+                        const PTri* tp = reinterpret_cast<const PTri*>(reinterpret_cast<const char*>(S.ptris) + (uint32_t)(idx * (uint32_t)sizeof(PTri)));
                         if (COUNT) ++np;
                         const uint32_t orig = tp->orig; // rides in the request that brings v2.z
                         double t, u, v;

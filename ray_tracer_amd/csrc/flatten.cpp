@@ -786,7 +786,9 @@ struct Flattener {
                     n.qhi[a][k] = k < n_all ? c.qhi[a][order[k]] : 0;
                 }
             const uint32_t node_base = (uint32_t)f.pnodes.size(), leaf_base = (uint32_t)f.ptris.size();
-            if ((uint64_t)node_base + 4u >= (1ull << 28) || (uint64_t)leaf_base + 4u >= (1ull << 28)) { f.pnodes.clear(); f.ptris.clear(); return; }
+            // (the kernel addresses both arrays by 32-bit byte offsets: they stay below 4 GB, i.e. 2^25 triangles; larger
+            // meshes keep the 64-byte nodes)
+            if (((uint64_t)node_base + 4u) * sizeof(PNode) >= (1ull << 32) || ((uint64_t)leaf_base + 4u) * sizeof(PTri) >= (1ull << 32)) { f.pnodes.clear(); f.ptris.clear(); return; }
             n.node_base = make_ref(REF_QNODE, node_base);
             n.leaf_base = make_ref(RT_REF_TRI, leaf_base) - (uint32_t)n_inner;
             for (int k = 0; k < n_inner; ++k) {
