@@ -182,6 +182,13 @@ __global__ __launch_bounds__(FAST_BLOCK, (FMT == NODES_PACKED && PREP && !COUNT)
     unsigned long long c_refill = 0, c_node = 0, c_leaf = 0, c_pop = 0, c_mark = 0; // wave cycles per phase (s_memtime)
 #define RT_TICK(acc) do { if (COUNT) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); (acc) += now_ - c_mark; c_mark = now_; } } while (0)
     if (COUNT) c_mark = __builtin_amdgcn_s_memtime();
+    // (COUNT builds: when the launch's first wave started, when the first wave found the batch used up, when the last
+    // wave ended, on the 100 MHz clock all CUs share; stored as maxima of a zero-initialised word)
+    constexpr unsigned long long T_BIG = 1ull << 62;
+    bool d_end_noted = false;
+    uint32_t d_ray_iters = 0, d_ray_iters_max = 0;
+    const unsigned long long d_t_start = COUNT ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    if (COUNT && lane == 0) atomicMax(&stat_counters[17], T_BIG - __builtin_amdgcn_s_memrealtime());
     uint32_t d_iters = 0, d_node_lanes = 0, d_tri_phases = 0, d_tri_lanes = 0, d_pop_iters = 0, d_pop_lanes = 0, d_rounds = 0, d_run_lanes = 0;
 
     for (;;) {
@@ -202,6 +209,7 @@ __global__ __launch_bounds__(FAST_BLOCK, (FMT == NODES_PACKED && PREP && !COUNT)
                     wave_end = wave_next + (unsigned long long)chunk;
                     if (wave_end > n) wave_end = n;
                     if (wave_next >= n) { wave_next = wave_end = n; more = false; }
+                    if (COUNT && !more && !d_end_noted) { d_end_noted = true; if ((int)lane == leader) atomicMax(&stat_counters[18], T_BIG - __builtin_amdgcn_s_memrealtime()); }
                 }
                 if (!active) {
                     const unsigned long long qi = wave_next + (unsigned long long)__builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u)); // idle lanes below this one
@@ -275,6 +283,7 @@ __global__ __launch_bounds__(FAST_BLOCK, (FMT == NODES_PACKED && PREP && !COUNT)
             // Holding primitive tests back until a quorum is reached keeps the f64 intersector from
             // running with a handful of lanes while the rest of the wave waits.
             const bool at_node = active && !pop && (cur >> 28) == REF_QNODE;
+            if (COUNT && active) ++d_ray_iters;
             if (COUNT) { ++d_iters; d_run_lanes += __popcll(RT_BALLOT(active)); d_node_lanes += __popcll(RT_BALLOT(at_node)); }
             if (at_node) {
                 uint4 ch = make_uint4(0u, 0u, 0u, 0u);
@@ -459,6 +468,7 @@ __global__ __launch_bounds__(FAST_BLOCK, (FMT == NODES_PACKED && PREP && !COUNT)
                         asm volatile("" : "+v"(slot)); // the two addresses are formed here, once per ray, not kept in registers from the refill on
                         out_t[(unsigned long long)slot * OUT_T_STRIDE] = best_ref == RT_REF_NONE ? D_INF : best_t;
                         out_prim[(unsigned long long)slot * OUT_PRIM_STRIDE] = best_ref;
+                        if (COUNT) { d_ray_iters_max = d_ray_iters > d_ray_iters_max ? d_ray_iters : d_ray_iters_max; d_ray_iters = 0; }
                         active = false;
                         pop = false;
                         break;
@@ -476,7 +486,9 @@ __global__ __launch_bounds__(FAST_BLOCK, (FMT == NODES_PACKED && PREP && !COUNT)
             if (running == 0 || (more && running < refill_threshold)) break;
         }
     }
+    const unsigned long long d_t_end = COUNT ? __builtin_amdgcn_s_memrealtime() : 0ull; // (before the statistics below, whose atomics queue up)
     if (COUNT) {
+        atomicMax(&stat_counters[3], (unsigned long long)d_ray_iters_max);
         atomicAdd(&stat_counters[0], (unsigned long long)nn);
         atomicAdd(&stat_counters[1], (unsigned long long)np);
         if (lane == 0) { // per-wave values: the ballots above are wave-uniform
@@ -492,6 +504,8 @@ __global__ __launch_bounds__(FAST_BLOCK, (FMT == NODES_PACKED && PREP && !COUNT)
             atomicAdd(&stat_counters[13], c_node);
             atomicAdd(&stat_counters[14], c_leaf);
             atomicAdd(&stat_counters[15], c_pop);
+            atomicMax(&stat_counters[19], d_t_end);
+            atomicMax(&stat_counters[16], d_t_start);
         }
     }
 }

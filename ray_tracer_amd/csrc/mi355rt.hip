@@ -910,7 +910,8 @@ int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit
         // large batches are binned by origin cell and prepared first (reorder.h); the allocation-free entry point
         // (ctx_scratch given) never grows the pass's scratch and so goes without it
         const bool reorder = tn.reorder && !ctx_scratch && n >= tn.reorder_min && n <= 0xFFFFFFFFull;
-        if (reorder) fblocks = (int)std::min<uint64_t>((uint64_t)s->fast_grid_blocks_prep, (waves + (FAST_BLOCK / 64) - 1) / (FAST_BLOCK / 64));
+        if (reorder && !(flags & RT_HIT_COUNTERS)) fblocks = (int)std::min<uint64_t>((uint64_t)s->fast_grid_blocks_prep, // (the counting variant has more registers: it keeps the smaller grid)
+                                                                                 (waves + (FAST_BLOCK / 64) - 1) / (FAST_BLOCK / 64));
         if (reorder) {
             int rc = ensure_reorder_scratch(s, n);
             if (rc) return rc;
@@ -930,7 +931,14 @@ int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit
         // lanes go on past a primitive they have reached where a ray crosses many triangle boxes (bvh_kernel.h);
         // measured: the 2^20-triangle soup (overlap 70) gains 3 %, a closed surface of 1.3 M triangles (overlap 3.9) loses 3 %
         const int postpone = tn.postpone >= 0 ? tn.postpone : (fmt == NODES_PACKED && reorder && s->flat.fast_leaf_overlap > POSTPONE_MIN_OVERLAP ? 1 : 0);
-        hipLaunchKernelGGL(reorder ? fast_kernel_prepared(s->fast_prim, count, fmt) : fast_kernel(s->fast_prim, count, fmt),
+        const FastKernel kernel = reorder ? fast_kernel_prepared(s->fast_prim, count, fmt) : fast_kernel(s->fast_prim, count, fmt);
+        if (count) { // the counting variants have more registers than the grids are sized for: every workgroup of a launch must be resident
+            int per_cu = 0, cus = 0;
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, FAST_BLOCK, 0));
+            HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device));
+            fblocks = std::min(fblocks, std::max(1, per_cu * cus));
+        }
+        hipLaunchKernelGGL(kernel,
                            dim3(fblocks), dim3(FAST_BLOCK), 0, st, s->dev, entry, *rays, (unsigned long long)n, rq, opt, 0.001,
                            s->fast_extent, hits->t, hits->prim, s->d_counters + C_WORK_SLOTS, s->d_counters + C_NODES, s->fast_spill,
                            reorder ? tn.prep_refill : tn.refill, reorder ? tn.prep_vote : tn.vote, tn.chunk, postpone, (const PRay*)s->prep);
@@ -1460,6 +1468,10 @@ int rt_get_counters(rt_scene* s, rt_counters* out) {
                          s->h_counters[8], s->h_counters[9], s->h_counters[10], s->h_counters[11], s->h_counters[12], s->h_counters[13], s->h_counters[14], s->h_counters[15]);
             std::fprintf(stderr, "[mi355rt] wave cycles (s_memtime, summed over waves): refill %llu node %llu leaf %llu pop %llu (64-ray pieces %llu)\n", s->h_counters[16],
                          s->h_counters[17], s->h_counters[18], s->h_counters[19], s->h_counters[20]);
+            if (s->h_counters[23]) { // primitive-BVH kernel, counting build: the launch's ends on the 100 MHz clock
+                const double t0 = (double)((1ull << 62) - s->h_counters[21]), t1 = (double)((1ull << 62) - s->h_counters[22]), t2 = (double)s->h_counters[23];
+                std::fprintf(stderr, "[mi355rt] launch timeline (us): first wave starts 0, last wave starts %.1f, first wave finds the batch used up %.1f, last wave ends %.1f; longest ray %llu iterations\n", ((double)s->h_counters[20] - t0) / 100.0, (t1 - t0) / 100.0, (t2 - t0) / 100.0, s->h_counters[7]);
+            }
         }
     }
     *out = s->counters;
