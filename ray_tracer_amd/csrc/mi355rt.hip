@@ -564,7 +564,7 @@ struct Tuning {
     bool packed = true;          // MI355RT_PACKED=0: keep the 64-byte 8-bit nodes where the 48-byte packed tree exists
     bool fast_extend = true;     // MI355RT_FAST_EXTEND=0: the renderer keeps the general traversal
     bool shade_textures = false; // MI355RT_SHADE_TEXTURES=1: always the full shading kernel
-    bool reorder = true;         // MI355RT_REORDER=0: no binning pass in front of large closest-hit batches
+    int reorder = 1;             // MI355RT_REORDER: binning pass in front of large closest-hit batches: 0 never, 1 where it pays (below), 2 always
     bool debug = false;          // MI355RT_DEBUG: diagnostics on stderr
     uint64_t device_bvh_min = 1ull << 15; // MI355RT_DEVICE_BVH_MIN: BVHs over at least this many objects are built on the device (0 = never)
     int fast_blocks_per_cu = 0;  // MI355RT_FAST_BLOCKS_PER_CU: cap on the primitive-BVH kernel's workgroups per CU (occupancy experiments)
@@ -694,7 +694,7 @@ Tuning read_tuning() {
     t.quant = env_int("MI355RT_QUANT", 1) != 0;
     t.fast_extend = env_int("MI355RT_FAST_EXTEND", 1) != 0;
     t.shade_textures = env_int("MI355RT_SHADE_TEXTURES", 0) != 0;
-    t.reorder = env_int("MI355RT_REORDER", 1) != 0;
+    t.reorder = env_int("MI355RT_REORDER", 1);
     t.debug = getenv("MI355RT_DEBUG") != nullptr;
     t.fast_blocks_per_cu = env_int("MI355RT_FAST_BLOCKS_PER_CU", 0);
     t.device_bvh_min = (uint64_t)std::max(0, env_int("MI355RT_DEVICE_BVH_MIN", (int)t.device_bvh_min));
@@ -909,7 +909,12 @@ int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit
         const uint32_t opt = (rays->time ? 1u : 0u) | (rays->tmin ? 2u : 0u) | (rays->tmax ? 4u : 0u);
         // large batches are binned by origin cell and prepared first (reorder.h); the allocation-free entry point
         // (ctx_scratch given) never grows the pass's scratch and so goes without it
-        const bool reorder = tn.reorder && !ctx_scratch && n >= tn.reorder_min && n <= 0xFFFFFFFFull;
+        // The pass costs 0.7 ms per 2^24 rays and buys locality and a cheaper refill.  That pays where a ray crosses many
+        // leaf boxes, i.e. walks long: on the 2^20-triangle soup (leaf overlap 70) a step takes 7.1 instead of 9.4 ms; on a
+        // closed surface of 1.3 M triangles (overlap 3.9) the traversal gains 0.1 ms and the step loses 0.6, and every
+        // sphere scene measured loses too (486 spheres: half the rate).  So: packed trees whose leaf overlap is high.
+        const bool pays = tn.reorder >= 2 || (s->fast_fmt == NODES_PACKED && s->flat.fast_leaf_overlap > POSTPONE_MIN_OVERLAP);
+        const bool reorder = tn.reorder && pays && !ctx_scratch && n >= tn.reorder_min && n <= 0xFFFFFFFFull;
         if (reorder && !(flags & RT_HIT_COUNTERS)) fblocks = (int)std::min<uint64_t>((uint64_t)s->fast_grid_blocks_prep, // (the counting variant has more registers: it keeps the smaller grid)
                                                                                  (waves + (FAST_BLOCK / 64) - 1) / (FAST_BLOCK / 64));
         if (reorder) {

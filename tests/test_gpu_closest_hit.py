@@ -423,6 +423,7 @@ def test_prepared_rays_of_the_packed_tree(monkeypatch):
     m = rt.Lambertian(rt.Color(.5, .5, .5))
     desc = rt.SceneDesc.from_world(rt.Mesh(scenes.triangle_soup(6000, seed=51, edge=0.07), m))
     monkeypatch.setenv("MI355RT_REORDER_MIN", "1")
+    monkeypatch.setenv("MI355RT_REORDER", "2")  # also where the pass would not pay
     o, d = _edge_rays([0, 1, 0, 1, 0, 1])
     compare(desc, o, d, min_hits=300, flags=F.RT_HIT_ORDERED)
     oo, dd, tm = scenes.incoherent_rays(30000, [-0.2, 1.2, -0.2, 1.2, -0.2, 1.2], seed=52)
