@@ -557,7 +557,7 @@ __global__ __launch_bounds__(BLOCK) void accumulate_kernel(PathState ps, BatchGe
 // ============================================================================ host code
 // Measurement switches, read from the environment ONCE, when a scene is created (never per launch).
 struct Tuning {
-    int refill = REFILL_THRESHOLD, vote = LEAF_VOTE, chunk = 0; // primitive-BVH kernel scheduling
+    int refill = -1, vote = -1, chunk = 0; // primitive-BVH kernel scheduling (MI355RT_REFILL, MI355RT_VOTE, MI355RT_CHUNK; -1 / 0: the defaults of bvh_kernel.h)
     int prep_refill = PREP_REFILL_THRESHOLD, prep_vote = PREP_LEAF_VOTE;               // the same for reordered batches
     bool quant = true;           // MI355RT_QUANT=0: keep the f32 4-wide nodes
     int postpone = -1;           // MI355RT_POSTPONE=0/1: overrides the choice made from the tree (postponed primitive tests)
@@ -934,8 +934,10 @@ int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit
         const int fmt = (s->fast_fmt == NODES_PACKED && (opt & 2u)) ? NODES_8BIT : s->fast_fmt;
         const uint32_t entry = fmt == s->fast_fmt ? s->fast_entry : s->flat.fast_root;
         // lanes go on past a primitive they have reached where a ray crosses many triangle boxes (bvh_kernel.h);
-        // measured: the 2^20-triangle soup (overlap 70) gains 3 %, a closed surface of 1.3 M triangles (overlap 3.9) loses 3 %
-        const int postpone = tn.postpone >= 0 ? tn.postpone : (fmt == NODES_PACKED && reorder && s->flat.fast_leaf_overlap > POSTPONE_MIN_OVERLAP ? 1 : 0);
+        // measured on reordered batches: the 2^20-triangle soup (overlap 70) gains 3 %, a closed surface of 1.3 M triangles
+        // (overlap 3.9) loses 3 %; on batches traced as they come closed surfaces of 82 k and 1.3 M triangles gain 1-3 %
+        const int postpone = tn.postpone >= 0 ? tn.postpone : (fmt == NODES_PACKED && (!reorder || s->flat.fast_leaf_overlap > POSTPONE_MIN_OVERLAP) ? 1 : 0);
+        const int refill = reorder ? tn.prep_refill : (tn.refill >= 0 ? tn.refill : HIT_REFILL_THRESHOLD), vote = reorder ? tn.prep_vote : (tn.vote >= 0 ? tn.vote : HIT_LEAF_VOTE);
         const FastKernel kernel = reorder ? fast_kernel_prepared(s->fast_prim, count, fmt) : fast_kernel(s->fast_prim, count, fmt);
         if (count) { // the counting variants have more registers than the grids are sized for: every workgroup of a launch must be resident
             int per_cu = 0, cus = 0;
@@ -946,7 +948,7 @@ int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit
         hipLaunchKernelGGL(kernel,
                            dim3(fblocks), dim3(FAST_BLOCK), 0, st, s->dev, entry, *rays, (unsigned long long)n, rq, opt, 0.001,
                            s->fast_extent, hits->t, hits->prim, s->d_counters + C_WORK_SLOTS, s->d_counters + C_NODES, s->fast_spill,
-                           reorder ? tn.prep_refill : tn.refill, reorder ? tn.prep_vote : tn.vote, tn.chunk, postpone, (const PRay*)s->prep);
+                           refill, vote, tn.chunk, postpone, (const PRay*)s->prep);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev[2], st));
         if (hits->u || hits->v || hits->front_face || hits->mat || hits->nx || hits->ny || hits->nz || hits->px || hits->py || hits->pz)
@@ -976,7 +978,7 @@ int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit
         const uint32_t opt = (rays->time ? 1u : 0u) | (rays->tmin ? 2u : 0u) | (rays->tmax ? 4u : 0u);
         hipLaunchKernelGGL(fast_kernel(s->fast_prim, false, s->fast_fmt), dim3(fblocks), dim3(FAST_BLOCK), 0, st, s->dev, s->fast_entry, *rays,
                            (unsigned long long)n, rq, opt, 0.001, s->fast_extent, hits->t, hits->prim, s->d_counters + C_WORK_SLOTS, s->d_counters + C_NODES,
-                           s->fast_spill, tn.refill, tn.vote, tn.chunk, 0, (const PRay*)nullptr);
+                           s->fast_spill, tn.refill >= 0 ? tn.refill : HIT_REFILL_THRESHOLD, tn.vote >= 0 ? tn.vote : HIT_LEAF_VOTE, tn.chunk, 0, (const PRay*)nullptr);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemsetAsync(s->d_counters + C_WORK_SLOTS, 0, WORK_SLOTS * WORK_STRIDE * sizeof(unsigned long long), st));
     }
@@ -1063,7 +1065,7 @@ int render_impl(rt_scene* s, const rt_camera* cam, uint64_t seed, const rt_work*
             const bool rr = cam->russian_roulette != 0;
             const int media = s->flat.medium_depth > 1 ? 2 : (s->flat.has_medium ? 1 : 0);
             const uint64_t tail_paths = s->tune.tail_paths;
-            const int k_refill = s->tune.refill, k_vote = s->tune.vote, k_chunk = s->tune.chunk;
+            const int k_refill = s->tune.refill >= 0 ? s->tune.refill : REFILL_THRESHOLD, k_vote = s->tune.vote >= 0 ? s->tune.vote : LEAF_VOTE, k_chunk = s->tune.chunk;
             bool live_exact = true; // `live` is the device's count (it is refreshed only now and then)
             for (int32_t bounce = 0; bounce < cam->max_depth && live > 0; ++bounce) {
                 if (live_exact && bounce > 0 && live <= tail_paths) {

@@ -408,8 +408,10 @@ def test_packed_and_64_byte_nodes_agree(monkeypatch):
         for k in ("u", "v", "front_face", "mat"):
             assert np.array_equal(a[k][same], b[k][same]), k
     ca, cb = packed.counters(), plain.counters()
-    # (children with equal entry distances may be visited in another order: the counts agree closely, not exactly)
-    assert abs(int(ca.node_visits) - int(cb.node_visits)) <= 0.01 * cb.node_visits and ca.prim_tests > 0
+    # (children with equal entry distances may be visited in another order, and the packed kernel lets a lane walk on past
+    # a triangle it has reached until enough lanes have one to test, which costs it a few node visits: the counts agree
+    # closely, not exactly)
+    assert abs(int(ca.node_visits) - int(cb.node_visits)) <= 0.03 * cb.node_visits and ca.prim_tests > 0
     compare(desc, o[:5000], d[:5000], min_hits=1000, flags=F.RT_HIT_ORDERED)
     packed.close(); plain.close()
 
