@@ -279,14 +279,27 @@ typedef struct rt_hit_batch {
 
 /* Random numbers drawn inside traversal (constant_medium.rs:90) come from the
  * counter-based stream (seed, stream 2, ray index); see rt_rng_uniform.
- * One call in flight per scene: a scene owns one set of work counters, one path workspace and one set of
- * timing events, so two rt_closest_hit* / rt_render* calls on the same rt_scene must not overlap, whatever
- * streams they use (different scenes are independent).  The *_device entry points enqueue and return. */
+ * Threads and streams: rt_closest_hit* / rt_render* may be called on one scene from several host threads and on
+ * several streams at once, as the reference calls world.hit from every rayon worker (camera.rs:99).  A scene owns
+ * one set of work counters, scratch buffers and timing events, so the library puts such calls in a row: a mutex of
+ * the scene is held while a call enqueues (to the end of the call for the host-pointer entry points, which wait
+ * for their results), and a call's first launch waits on the device for the previous call on that scene when the
+ * two use different streams.  Calls on different scenes are independent.  rt_closest_hit_device_noalloc is the
+ * exception on the device side (see there).
+ * The *_device entry points enqueue and return.  They grow the scene's scratch (4 bytes per ray of transform
+ * context; for large batches on some triangle meshes 66 bytes per ray for the binning pass; the path workspace of
+ * a render) with hipMalloc, synchronously, when a call needs more than any call before it; rt_scene_reserve sizes
+ * all of it ahead of time, after which calls within those sizes allocate nothing. */
 int rt_closest_hit(rt_scene* scene, const rt_ray_batch* rays, uint64_t n,
                    rt_hit_batch* hits, uint64_t seed, uint32_t flags);          /* host pointers */
 int rt_closest_hit_device(rt_scene* scene, const rt_ray_batch* rays, uint64_t n,
                           rt_hit_batch* hits, uint64_t seed, uint32_t flags,
                           void* hip_stream);                                     /* device pointers */
+
+/* No counterpart in the reference (Rust allocates where it needs to).  Sizes the scene's scratch for closest-hit
+ * batches of up to max_rays rays and render batches of up to max_paths paths (0: leave as it is), so that later
+ * *_device calls within those sizes only enqueue.  Waits for the device first. */
+int rt_scene_reserve(rt_scene* scene, uint64_t max_rays, uint64_t max_paths);
 
 /* No counterpart in the reference.  For callers that cannot allocate device memory while they call (code
  * under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): the same query as
@@ -379,6 +392,8 @@ typedef struct rt_counters {
     double   ms_sum_traversal;    /* events of the 32 newest calls between two rt_get_counters; older ones are not counted) */
     double   ms_sum_reorder;
     uint64_t timed_calls;         /* number of calls in those sums */
+    uint64_t shader_khz;          /* shader clock during the last primitive-BVH launch with RT_HIT_COUNTERS (a wave's cycle counter
+                                     against the constant 100 MHz counter); 0 until such a launch has run */
 } rt_counters;
 
 int rt_get_counters(rt_scene* scene, rt_counters* out);

@@ -137,7 +137,7 @@ class rt_counters(C.Structure):
                 ("render_rays", C.c_uint64), ("extend_launches", C.c_uint64), ("ms_last_closest_hit", C.c_double),
                 ("ms_last_render", C.c_double), ("ms_last_traversal", C.c_double), ("ms_last_reorder", C.c_double),
                 ("ms_sum_closest_hit", C.c_double), ("ms_sum_traversal", C.c_double), ("ms_sum_reorder", C.c_double),
-                ("timed_calls", C.c_uint64)]
+                ("timed_calls", C.c_uint64), ("shader_khz", C.c_uint64)]
 
 
 # Every symbol include/mi355rt.h declares, with its prototype.
@@ -153,6 +153,7 @@ PROTOTYPES = {
     "rt_scene_object_bounds": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_double)]),
     "rt_obj_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.c_int32, C.POINTER(C.POINTER(rt_triangle)), C.POINTER(C.c_uint64)]),
     "rt_obj_free": (None, [C.POINTER(rt_triangle)]),
+    "rt_scene_reserve": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64]),
     "rt_closest_hit": (C.c_int, [C.c_void_p, C.POINTER(rt_ray_batch), C.c_uint64, C.POINTER(rt_hit_batch), C.c_uint64, C.c_uint32]),
     "rt_closest_hit_device": (C.c_int, [C.c_void_p, C.POINTER(rt_ray_batch), C.c_uint64, C.POINTER(rt_hit_batch), C.c_uint64, C.c_uint32, C.c_void_p]),
     "rt_closest_hit_device_noalloc": (C.c_int, [C.c_void_p, C.POINTER(rt_ray_batch), C.c_uint64, C.POINTER(rt_hit_batch), C.c_uint64, C.c_uint32, C.c_void_p]),

@@ -195,6 +195,7 @@ __global__ __launch_bounds__(FAST_BLOCK, (FMT == NODES_PACKED && PREP && !COUNT)
     bool d_end_noted = false;
     uint32_t d_ray_iters = 0, d_ray_iters_max = 0;
     const unsigned long long d_t_start = COUNT ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const unsigned long long d_c_start = COUNT ? __builtin_amdgcn_s_memtime() : 0ull; // shader-clock cycles, against the 100 MHz clock above
     if (COUNT && lane == 0) atomicMax(&stat_counters[17], T_BIG - __builtin_amdgcn_s_memrealtime());
     uint32_t d_iters = 0, d_node_lanes = 0, d_tri_phases = 0, d_tri_lanes = 0, d_pop_iters = 0, d_pop_lanes = 0, d_rounds = 0, d_run_lanes = 0;
 
@@ -376,9 +377,13 @@ __global__ __launch_bounds__(FAST_BLOCK, (FMT == NODES_PACKED && PREP && !COUNT)
                     if (k[0] != 0xFFFFFFFFu) {
                         const bool h1 = k[1] != 0xFFFFFFFFu, h2 = k[2] != 0xFFFFFFFFu, h3 = k[3] != 0xFFFFFFFFu;
                         RT_STACK_RESERVE(st, (h1 ? 1 : 0) + (h2 ? 1 : 0) + (h3 ? 1 : 0));
-                        if (h3) RT_STACK_PUSH(st, RT_SLOT_REF(k[3]), __uint_as_float(k[3]));
-                        if (h2) RT_STACK_PUSH(st, RT_SLOT_REF(k[2]), __uint_as_float(k[2]));
-                        if (h1) RT_STACK_PUSH(st, RT_SLOT_REF(k[1]), __uint_as_float(k[1]));
+                        // (the slot bits are cleared again before the key becomes the deferred child's entry distance: with
+                        // them the stored value could lie up to three units in the last place ABOVE the computed distance,
+                        // more than the slab test's margin covers, and the pop-time cull could drop a subtree whose triangle
+                        // ties with, or lies a hair in front of, the closest hit so far)
+                        if (h3) RT_STACK_PUSH(st, RT_SLOT_REF(k[3]), __uint_as_float(k[3] & ~3u));
+                        if (h2) RT_STACK_PUSH(st, RT_SLOT_REF(k[2]), __uint_as_float(k[2] & ~3u));
+                        if (h1) RT_STACK_PUSH(st, RT_SLOT_REF(k[1]), __uint_as_float(k[1] & ~3u));
                         cur = RT_SLOT_REF(k[0]);
                     } else {
                         pop = true;
@@ -513,6 +518,9 @@ __global__ __launch_bounds__(FAST_BLOCK, (FMT == NODES_PACKED && PREP && !COUNT)
             atomicAdd(&stat_counters[15], c_pop);
             atomicMax(&stat_counters[19], d_t_end);
             atomicMax(&stat_counters[16], d_t_start);
+            // the shader clock this wave ran at, in kHz: its cycle counter against the constant 100 MHz counter over its lifetime
+            const unsigned long long d_cycles = __builtin_amdgcn_s_memtime() - d_c_start, d_ticks = __builtin_amdgcn_s_memrealtime() - d_t_start;
+            if (d_ticks > 1000ull) atomicMax(&stat_counters[20], d_cycles * 100000ull / d_ticks);
         }
     }
 }

@@ -23,8 +23,8 @@
 #include <string>
 #include <vector>
 
-#include "flatten.h"
-#include "shade.h"
+#define RT_REORDER_KERNELS
+#include "rt_internal.h"
 #include "bvh_kernel.h"
 
 using namespace rt;
@@ -38,120 +38,6 @@ static __device__ __align__(256) int32_t scratch[NOALLOC_MAX_RAYS];
 
 // ============================================================================ device code
 namespace {
-
-constexpr int TAIL_PATHS = 1 << 16; // a batch with this many live paths or fewer finishes in one launch (tail_kernel)
-constexpr unsigned long long RANGES_PER_WAVE = 8ull; // work ranges a wave of a persistent kernel gets on average
-enum { C_WORK = 0, C_LIVE_IN = 1, C_LIVE_OUT = 2, C_NODES = 4, C_PRIMS = 5, C_RAYS = 6, C_WORDS = 32 };
-// Work counters of the general persistent kernels: one per XCD, each on a 128-byte line of its own, behind the
-// C_WORDS statistics words.
-// (The primitive-BVH kernel is handed the first slot and addresses them as work_counter + (workgroup % 8) * 16.)
-constexpr int WORK_SLOTS = 8, WORK_STRIDE = 16, C_WORK_SLOTS = 32, C_ALLOC = C_WORK_SLOTS + WORK_SLOTS * WORK_STRIDE;
-
-struct CamD { // Camera after initialize() (camera.rs:30-42)
-    rt_camera_derived d;
-    double defocus_angle;
-    double background[3];
-    int32_t image_width;
-    int32_t russian_roulette;
-};
-
-// One path = one 128-byte line in HBM.  The queues permute the paths after the first bounce, so every
-// kernel gathers its paths by index: with one array per field that was seventeen 8-byte gathers (seventeen
-// lines) per path and bounce, with one record it is a single line read and written once per kernel.
-struct alignas(128) PathRec {
-    double o[3], d[3];  // current ray (ray.rs:5-9)
-    double time;
-    double beta[3];     // throughput
-    double L[3];        // accumulated radiance
-    uint32_t rng_index; // draws taken so far from the path's stream
-    uint32_t _pad;
-    double hit_t;       // result of the last extend: the last 16 bytes of the line, written with one store
-    uint32_t hit_ref;
-    int32_t hit_ctx;
-};
-static_assert(sizeof(PathRec) == 128, "a path is one cache line");
-static_assert(offsetof(PathRec, hit_t) == 112, "the hit block is one aligned 16-byte store");
-constexpr uint64_t PATH_DOUBLES = sizeof(PathRec) / sizeof(double);
-
-struct PathState {
-    PathRec* rec;
-    uint32_t* queue[2];
-    unsigned long long* counters;
-    double2* uv;   // per path: the u,v a constant-medium hit reports (null unless some phase function reads them: traverse.h UvTrack)
-};
-
-// The world ray of path p as the traversal and the record completion read it (strided view of the records).
-__device__ __forceinline__ WorldRay path_ray(const PathState& ps, uint32_t p) {
-    const double* b = reinterpret_cast<const double*>(ps.rec);
-    return WorldRay{b + 0, b + 1, b + 2, b + 3, b + 4, b + 5, (uint64_t)p * PATH_DOUBLES};
-}
-
-struct BatchGeom { // which (pixel, stratum) a path slot stands for
-    int32_t x0, y0, tw, th;        // tile origin and size
-    int32_t sample0, nsamples;     // strata [sample0, sample0 + nsamples)
-    uint32_t npix;                 // tw * th
-    uint32_t npaths;               // npix * nsamples
-};
-
-__device__ __forceinline__ unsigned long long wave_fetch(unsigned long long* counter, unsigned long long amount) {
-    unsigned long long base = 0;
-    if ((threadIdx.x & 63u) == 0u) base = atomicAdd(counter, amount);
-    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)base);
-    uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
-    return ((unsigned long long)hi << 32) | lo;
-}
-
-// Work distribution of the persistent kernels.  The chip serves same-address atomics at roughly 10 ns each:
-// with one counter for all waves, one atomic per 64 rays caps a kernel near 6 G rays/s, and at launch, when
-// every wave asks at the same moment, the last in line waits tens of microseconds.  So a range is up to 16
-// wave-loads (fewer when the batch is small, so that every wave still gets several ranges); wave w starts on
-// range w without asking anybody; after that the waves of XCD x (workgroups are dealt round-robin over the 8
-// XCDs) take the ranges waves + 8k + x, k from a counter of their own.  Ranges are still handed out in queue
-// order, so at any moment the whole chip works on one window of the queue, which keeps the path records it
-// gathers close together in HBM (an even static split, every wave streaming through a region of its own,
-// was 8 % slower; so was looking at the counter with a plain load before paying for the last atomic).
-// The last quarter of the batch is handed out in ranges a quarter as long: a launch ends when its last range
-// does, and with ~8 ranges per wave a full-length last range is an eighth of the launch.
-struct WaveWork {
-    unsigned long long n, len, short_len, n_long, waves, wave_id;
-    uint32_t slot, slots;
-    bool started;
-    __device__ __forceinline__ WaveWork(unsigned long long n_) : n(n_), started(false) {
-        waves = (unsigned long long)gridDim.x * (blockDim.x / 64u);
-        wave_id = (unsigned long long)blockIdx.x * (blockDim.x / 64u) + (threadIdx.x >> 6);
-        const unsigned long long k = n / (waves * RANGES_PER_WAVE * 64ull);
-        len = 64ull * (k < 1ull ? 1ull : (k > 16ull ? 16ull : k));
-        short_len = 64ull * (len / 256ull < 1ull ? 1ull : len / 256ull);
-        n_long = (n - n / 4ull) / len; // ranges of full length; range g >= n_long starts at n_long*len + (g - n_long)*short_len
-        slots = gridDim.x < (uint32_t)WORK_SLOTS ? gridDim.x : (uint32_t)WORK_SLOTS; // every residue class needs a taker
-        slot = blockIdx.x % slots;
-    }
-    // Next range [base, base + length) of this wave; base >= n when the batch is finished.  `counters` is the
-    // scene's counter block (statistics words, then the work slots).
-    __device__ __forceinline__ unsigned long long next(unsigned long long* counters, unsigned long long& length) {
-        unsigned long long g; // index of the range in queue order
-        if (!started) { started = true; g = wave_id; }
-        else {
-            // cheap exit without an atomic when even this slot's first dynamic range lies beyond the batch
-            if (n_long * len + (waves + slot >= n_long ? (waves + slot - n_long) * short_len : 0ull) >= n && waves + slot >= n_long) { length = 0; return n; }
-            g = waves + slot + wave_fetch(counters + C_WORK_SLOTS + slot * WORK_STRIDE, 1ull) * (unsigned long long)slots;
-        }
-        if (g < n_long) { length = len; return g * len; }
-        length = short_len;
-        return n_long * len + (g - n_long) * short_len;
-    }
-};
-
-// u,v of the record a medium hit was written into: those of the primitive hit that last wrote it, or the default 0, 0.
-__device__ __forceinline__ void stale_uv(const DScene& S, const WorldRay& w, double time, const UvTrack& uvt, double& u, double& v) {
-    u = 0.0; v = 0.0;
-    if (uvt.ref == RT_REF_NONE) return;
-    Best b;
-    b.t = uvt.t; b.ref = uvt.ref; b.ctx = uvt.ctx;
-    HitRec h;
-    finalize(S, w, time, b, h, true);
-    u = h.u; v = h.v;
-}
 
 // MEDIA = 0: the scene holds no constant medium; the nested boundary queries and the random draw are compiled out.
 // UV: some phase function reads u,v, so the walk keeps track of whose u,v a medium hit inherits (traverse.h UvTrack).
@@ -210,415 +96,9 @@ __global__ __launch_bounds__(BLOCK) void closest_hit_kernel(DScene S, rt_ray_bat
     }
 }
 
-__global__ void init_batch_kernel(unsigned long long* counters, unsigned long long npaths) {
-    counters[C_WORK] = 0ull;
-    for (int k = 0; k < WORK_SLOTS; ++k) counters[C_WORK_SLOTS + k * WORK_STRIDE] = 0ull;
-    counters[C_LIVE_IN] = npaths;
-    counters[C_LIVE_OUT] = 0ull;
-}
-
-// After a bounce: the compacted queue becomes the input of the next one.
-// The counters are read and re-written in one kernel.  A uniform-address load goes through the
-// scalar cache while the store goes through the vector path, and nothing orders the two: the
-// plain form `in = c[OUT]; c[OUT] = 0` was observed to read the zero it stores.  Exchanges make
-// every read-modify-write a single memory operation.
-__global__ void advance_kernel(unsigned long long* counters) {
-    unsigned long long out = atomicExch(&counters[C_LIVE_OUT], 0ull);
-    unsigned long long in = atomicExch(&counters[C_LIVE_IN], out);
-    atomicAdd(&counters[C_RAYS], in);
-    atomicExch(&counters[C_WORK], 0ull);
-    for (int k = 0; k < WORK_SLOTS; ++k) atomicExch(&counters[C_WORK_SLOTS + k * WORK_STRIDE], 0ull);
-}
-
-__global__ void reset_work_kernel(unsigned long long* counters) {
-    counters[C_WORK] = 0ull;
-    for (int k = 0; k < WORK_SLOTS; ++k) counters[C_WORK_SLOTS + k * WORK_STRIDE] = 0ull;
-}
-
-__global__ __launch_bounds__(BLOCK) void raygen_kernel(CamD cam, BatchGeom bg, PathState ps, unsigned long long seed) {
-    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= bg.npaths) return;
-    uint32_t s_local = p / bg.npix, pix = p - s_local * bg.npix;
-    int32_t i = bg.x0 + (int32_t)(pix % (uint32_t)bg.tw);
-    int32_t j = bg.y0 + (int32_t)(pix / (uint32_t)bg.tw);
-    int32_t sidx = bg.sample0 + (int32_t)s_local;
-    int32_t s_j = sidx / cam.d.sqrt_spp, s_i = sidx % cam.d.sqrt_spp;
-    Rng g{seed, 0u, (uint32_t)(j * cam.image_width + i), (uint32_t)sidx, 0u};
-    // sample_square_stratified (camera.rs:227-231)
-    double px = (((double)s_i + g.next()) * cam.d.recip_sqrt_spp) - 0.5;
-    double py = (((double)s_j + g.next()) * cam.d.recip_sqrt_spp) - 0.5;
-    D3 pixel_sample = d3p(cam.d.pixel00_loc) + (((double)i + px) * d3p(cam.d.pixel_delta_u)) + (((double)j + py) * d3p(cam.d.pixel_delta_v));
-    D3 origin;
-    if (cam.defocus_angle <= 0.0) origin = d3p(cam.d.center);
-    else { // defocus_disk_sample (camera.rs:237-240)
-        D3 dsk = random_in_unit_disk(g);
-        origin = d3p(cam.d.center) + (dsk.x * d3p(cam.d.defocus_disk_u)) + (dsk.y * d3p(cam.d.defocus_disk_v));
-    }
-    D3 dir = pixel_sample - origin;
-    double time = g.next();
-    PathRec rec;
-    rec.o[0] = origin.x; rec.o[1] = origin.y; rec.o[2] = origin.z;
-    rec.d[0] = dir.x; rec.d[1] = dir.y; rec.d[2] = dir.z;
-    rec.time = time;
-    rec.beta[0] = 1.0; rec.beta[1] = 1.0; rec.beta[2] = 1.0;
-    rec.L[0] = 0.0; rec.L[1] = 0.0; rec.L[2] = 0.0;
-    rec.hit_t = D_INF; rec.hit_ref = RT_REF_NONE; rec.hit_ctx = 0;
-    rec.rng_index = g.index; rec._pad = 0;
-    ps.rec[p] = rec;
-    ps.queue[0][p] = p;
-}
-
-// MEDIA = false: the scene holds no constant medium, so the nested boundary queries and the random draw inside
-// traversal are compiled out (fewer registers, one more wave per SIMD).
-// At least 3 waves per SIMD (168 registers): the variant with media sits within a few registers of that limit,
-// and one wave less costs it more than 10 %.
-template <int MEDIA, bool UV = false>
-__global__ __launch_bounds__(BLOCK, 3) void extend_kernel(DScene S, PathState ps, int qsel, unsigned long long seed, BatchGeom bg, int32_t image_width,
-                                                          int rest_only) {
-    __shared__ uint32_t s_stack[STACK_MAX * BLOCK];
-    uint32_t* stk = s_stack + threadIdx.x;
-    const uint32_t lane = threadIdx.x & 63u;
-    const unsigned long long n = ps.counters[C_LIVE_IN];
-    const uint32_t* queue = ps.queue[qsel];
-    uint32_t nn = 0, np = 0;
-#ifdef RT_PHASE_STATS
-    if (threadIdx.x < 8) s_step_cycles[threadIdx.x] = 0ull;
-    __syncthreads();
-    unsigned long long ph[4] = {0ull, 0ull, 0ull, 0ull}, pieces = 0ull; // wave cycles: work fetch, record load, traversal, write-back
-#define RT_PHASE(k) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ph[k] += now_ - t_ph; t_ph = now_; } while (0)
-    unsigned long long t_ph = __builtin_amdgcn_s_memtime();
-#else
-#define RT_PHASE(k) do { } while (0)
-#endif
-    WaveWork work(n);
-    for (;;) {
-        unsigned long long chunk;
-        const unsigned long long base = work.next(ps.counters, chunk);
-        RT_PHASE(0);
-        if (base >= n) break;
-        uint32_t p_next = base + lane < n ? queue[base + lane] : 0u; // the queue entry is read one wave-load ahead of its record
-        for (unsigned long long off = 0; off < chunk; off += 64ull) {
-        unsigned long long q = base + off + lane;
-#ifdef RT_PHASE_STATS
-        if (base + off < n) ++pieces;
-#endif
-        const uint32_t p = p_next;
-        if (off + 64ull < chunk && q + 64ull < n) p_next = queue[q + 64ull];
-        if (q < n) {
-            PathRec* rec = ps.rec + p;
-            const WorldRay w = path_ray(ps, p);
-            RayD r;
-            ray_in_context(S, w, 0, r);
-            double time = rec->time;
-            RT_PHASE(1);
-            Best b;
-            b.t = D_INF; b.ref = RT_REF_NONE; b.ctx = 0;
-            uint32_t root = S.world;
-            if (rest_only) { // the primitive-BVH kernel has traced the world's first member: go on from its closest hit
-                b.t = rec->hit_t; b.ref = rec->hit_ref;
-                root = S.world_rest;
-            }
-            uint32_t s_local = p / bg.npix, pix = p - s_local * bg.npix;
-            int32_t i = bg.x0 + (int32_t)(pix % (uint32_t)bg.tw);
-            int32_t j = bg.y0 + (int32_t)(pix / (uint32_t)bg.tw);
-            Rng g{seed, 0u, (uint32_t)(j * image_width + i), (uint32_t)(bg.sample0 + (int32_t)s_local), rec->rng_index};
-#ifdef RT_PHASE_STATS
-            s_lane_iters[threadIdx.x] = 0u;
-#endif
-            UvTrack uvt;
-            uvt.ref = RT_REF_NONE; uvt.ctx = 0; uvt.t = 0.0; uvt.any = false;
-            traverse<MEDIA, false, true, true, MEDIA == 0, UV>(S, root, r, 0, w, time, 0.001, b, stk, 0, &g, nn, np, false, &uvt); // Interval::new(0.001, INFINITY) (camera.rs:258)
-            if (UV && b.ref != RT_REF_NONE && (b.ref >> 28) == RT_REF_MEDIUM) {
-                double2 uv;
-                stale_uv(S, w, time, uvt, uv.x, uv.y);
-                ps.uv[p] = uv;
-            }
-            RT_PHASE(2);
-#ifdef RT_PHASE_STATS
-            {
-                uint32_t it = s_lane_iters[threadIdx.x], mx = it, sm = it;
-                for (int o = 32; o > 0; o >>= 1) { uint32_t a = __shfl_xor(mx, o), c = __shfl_xor(sm, o); mx = a > mx ? a : mx; sm += c; }
-                const unsigned long long act = __popcll(__ballot(true));
-                if (lane == (uint32_t)__builtin_ctzll(__ballot(true))) { atomicAdd(&ps.counters[29], (unsigned long long)sm); atomicAdd(&ps.counters[30], (unsigned long long)mx * act); }
-            }
-#endif
-            uint4 hit_block; // hit_t, hit_ref, hit_ctx
-            hit_block.x = (uint32_t)__double2loint(b.t); hit_block.y = (uint32_t)__double2hiint(b.t);
-            hit_block.z = b.ref; hit_block.w = (uint32_t)b.ctx;
-            *reinterpret_cast<uint4*>(&rec->hit_t) = hit_block;
-            if (MEDIA) rec->rng_index = g.index; // only a constant medium draws during traversal (constant_medium.rs:90)
-            RT_PHASE(3);
-        }
-        }
-    }
-#ifdef RT_PHASE_STATS
-    if (lane == 0u) {
-        for (int k = 0; k < 4; ++k) atomicAdd(&ps.counters[16 + k], ph[k]);
-        atomicAdd(&ps.counters[20], pieces);
-    }
-    __syncthreads();
-    if (threadIdx.x < 8) atomicAdd(&ps.counters[8 + threadIdx.x], s_step_cycles[threadIdx.x]);
-#endif
-#undef RT_PHASE
-}
-
-constexpr int SHADE_ROUNDS = 16; // wave-loads of paths whose survivors share one queue reservation
-constexpr unsigned long long SHADE_GROUP = 4ull; // consecutive wave-loads a wave shades before it moves on by a stride of all waves
-// (two workgroups per CU: without the bound the textured variant needs 263 registers, seven over the limit for a
-// second wave per SIMD, which it is worth a few spilled values to keep)
-template <bool TEXTURES, bool RR>
-__global__ __launch_bounds__(BLOCK, 2) void shade_kernel(DScene S, CamD cam, PathState ps, int qsel, unsigned long long seed, BatchGeom bg, int last_bounce) {
-    const unsigned long long n = ps.counters[C_LIVE_IN];
-    const uint32_t* qin = ps.queue[qsel];
-    uint32_t* qout = ps.queue[qsel ^ 1];
-    // Survivors of up to SHADE_ROUNDS wave-loads are collected in LDS and get their place in the next queue
-    // with ONE atomic (all waves bump the same counter; one atomic per 64 paths capped this kernel).
-    __shared__ uint32_t s_keep[(BLOCK / 64) * SHADE_ROUNDS * 64];
-    uint32_t* keep = s_keep + (threadIdx.x >> 6) * (SHADE_ROUNDS * 64);
-    const uint32_t lane = threadIdx.x & 63u;
-    const unsigned long long waves = (unsigned long long)gridDim.x * (blockDim.x / 64u);
-    const unsigned long long wave_id = (unsigned long long)blockIdx.x * (blockDim.x / 64u) + (threadIdx.x >> 6);
-    // Wave w shades groups of SHADE_GROUP consecutive wave-loads, w, w + waves, w + 2*waves, ... in units of
-    // groups: no wave gets more than one group above its share (handing out whole chunks of 16 wave-loads left a
-    // quarter of the waves with 4 chunks and the rest with 3 at 12 M paths), at any moment the chip works on one
-    // window of the queue, and neighbours in the queue stay neighbours in the next one (single wave-loads
-    // interleaved across waves balance better still but cost the BVH scenes 3 %: the next bounce's waves
-    // then mix paths from distant parts of the frame).
-    const unsigned long long loads = (n + 63ull) / 64ull;
-    const unsigned long long groups = (loads + SHADE_GROUP - 1ull) / SHADE_GROUP;
-#ifdef RT_PHASE_STATS
-    unsigned long long ph[5] = {0ull, 0ull, 0ull, 0ull, 0ull}; // wave cycles: record load, hit record, material, write-back, queue
-#define RT_PHASE(k) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ph[k] += now_ - t_ph; t_ph = now_; } while (0)
-    unsigned long long t_ph = __builtin_amdgcn_s_memtime();
-#else
-#define RT_PHASE(k) do { } while (0)
-#endif
-    {
-        uint32_t kept = 0, rounds = 0; // wave-uniform
-        uint32_t p_next = wave_id * SHADE_GROUP * 64ull + lane < n ? qin[wave_id * SHADE_GROUP * 64ull + lane] : 0u; // the queue entry is read one wave-load ahead of its record
-        for (unsigned long long grp = wave_id; grp < groups; grp += waves)
-        for (unsigned long long load = grp * SHADE_GROUP; load < (grp + 1ull) * SHADE_GROUP && load < loads; ++load) {
-            const unsigned long long q = load * 64ull + lane;
-            bool alive = false;
-            const uint32_t p = p_next;
-            {
-                const unsigned long long q_next = load + 1ull < (grp + 1ull) * SHADE_GROUP ? q + 64ull : ((grp + waves) * SHADE_GROUP) * 64ull + lane;
-                if (q_next < n) p_next = qin[q_next];
-            }
-            if (q < n) {
-                PathRec* rec = ps.rec + p;
-                D3 beta = d3p(rec->beta);
-                D3 L = d3p(rec->L);
-                Best b;
-                b.t = rec->hit_t; b.ref = rec->hit_ref; b.ctx = rec->hit_ctx;
-                RT_PHASE(0);
-                if (b.ref == RT_REF_NONE) { // camera.rs:258-260
-                    L = L + beta * d3p(cam.background);
-                } else {
-                    RayD wr; // the world ray, read together with the rest of the record
-                    wr.ox = rec->o[0]; wr.oy = rec->o[1]; wr.oz = rec->o[2];
-                    wr.dx = rec->d[0]; wr.dy = rec->d[1]; wr.dz = rec->d[2];
-                    double time = rec->time;
-                    HitRec h;
-                    finalize(S, wr, time, b, h, TEXTURES && S.uses_uv != 0u); // only an image texture reads u,v (texture.rs:88-107)
-                    if (TEXTURES && ps.uv && (b.ref >> 28) == RT_REF_MEDIUM) { // a medium hit reports the u,v its record held (extend_kernel left them here)
-                        const double2 uv = ps.uv[p];
-                        h.u = uv.x; h.v = uv.y;
-                    }
-                    RT_PHASE(1);
-                    uint32_t s_local = p / bg.npix, pix = p - s_local * bg.npix;
-                    int32_t i = bg.x0 + (int32_t)(pix % (uint32_t)bg.tw);
-                    int32_t j = bg.y0 + (int32_t)(pix / (uint32_t)bg.tw);
-                    Rng g{seed, 0u, (uint32_t)(j * cam.image_width + i), (uint32_t)(bg.sample0 + (int32_t)s_local), rec->rng_index};
-                    D3 ray_dir = d3(wr.dx, wr.dy, wr.dz);
-                    D3 nd;
-                    alive = shade_hit<TEXTURES, RR>(S, h, ray_dir, g, beta, L, nd);
-                    RT_PHASE(2);
-                    if (alive) {
-                        if (last_bounce) { // the next ray_color call has depth 0 and returns black (camera.rs:252-254)
-                            L = L + beta * d3(0.0, 0.0, 0.0);
-                            alive = false;
-                        } else {
-                            rec->o[0] = h.p.x; rec->o[1] = h.p.y; rec->o[2] = h.p.z;
-                            rec->d[0] = nd.x; rec->d[1] = nd.y; rec->d[2] = nd.z;
-                            rec->beta[0] = beta.x; rec->beta[1] = beta.y; rec->beta[2] = beta.z;
-                            rec->rng_index = g.index;
-                        }
-                    }
-                }
-                rec->L[0] = L.x; rec->L[1] = L.y; rec->L[2] = L.z;
-            }
-            RT_PHASE(3);
-            const unsigned long long mask = __ballot(alive);
-            if (alive) keep[kept + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = p;
-            kept += (uint32_t)__popcll(mask);
-            ++rounds;
-            const bool last_of_wave = grp + waves >= groups && (load + 1ull == (grp + 1ull) * SHADE_GROUP || load + 1ull == loads);
-            if ((rounds == (uint32_t)SHADE_ROUNDS || last_of_wave) && kept) {
-                // the survivors collected so far take consecutive slots of the next queue
-                unsigned long long slot = 0;
-                if (lane == 0u) slot = atomicAdd(&ps.counters[C_LIVE_OUT], (unsigned long long)kept);
-                const uint32_t slot_lo = __builtin_amdgcn_readfirstlane((uint32_t)slot);
-                __builtin_amdgcn_wave_barrier();
-                for (uint32_t k = lane; k < kept; k += 64u) qout[slot_lo + k] = keep[k];
-                __builtin_amdgcn_wave_barrier();
-                kept = 0;
-            }
-            if (rounds == (uint32_t)SHADE_ROUNDS) rounds = 0;
-            RT_PHASE(4);
-        }
-    }
-#ifdef RT_PHASE_STATS
-    if (lane == 0u) for (int k = 0; k < 5; ++k) atomicAdd(&ps.counters[24 + k], ph[k]);
-#endif
-#undef RT_PHASE
-}
-
-// The last bounces of a batch in one launch.  Once few paths are left, every bounce is a pair of launches that
-// last as long as their slowest wave (170-200 us per bounce in a BVH scene, for tens of bounces), with the chip
-// nearly empty.  Here a lane keeps its path and alternates traversal and shading until the path ends: the batch
-// then takes as long as its slowest path, not the sum over bounces of each bounce's slowest wave.  Same device
-// functions in the same order as extend_kernel + shade_kernel, so the same bits.
-template <int MEDIA, bool TEXTURES, bool RR, bool UV = false>
-__global__ __launch_bounds__(BLOCK) void tail_kernel(DScene S, CamD cam, PathState ps, int qsel, unsigned long long seed, BatchGeom bg,
-                                                     int first_bounce, int max_depth) {
-    __shared__ uint32_t s_stack[STACK_MAX * BLOCK];
-    uint32_t* stk = s_stack + threadIdx.x;
-    const unsigned long long n = ps.counters[C_LIVE_IN];
-    const uint32_t* queue = ps.queue[qsel];
-    const unsigned long long threads = (unsigned long long)gridDim.x * blockDim.x;
-    unsigned long long traced = 0;
-    uint32_t nn = 0, np = 0;
-    for (unsigned long long q = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += threads) {
-        const uint32_t p = queue[q];
-        PathRec* rec = ps.rec + p;
-        const WorldRay w = path_ray(ps, p); // reads rec->o / rec->d: they are kept current in memory below
-        RayD r;
-        r.ox = rec->o[0]; r.oy = rec->o[1]; r.oz = rec->o[2];
-        r.dx = rec->d[0]; r.dy = rec->d[1]; r.dz = rec->d[2];
-        const double time = rec->time;
-        D3 beta = d3p(rec->beta);
-        D3 L = d3p(rec->L);
-        uint32_t s_local = p / bg.npix, pix = p - s_local * bg.npix;
-        int32_t i = bg.x0 + (int32_t)(pix % (uint32_t)bg.tw);
-        int32_t j = bg.y0 + (int32_t)(pix / (uint32_t)bg.tw);
-        Rng g{seed, 0u, (uint32_t)(j * cam.image_width + i), (uint32_t)(bg.sample0 + (int32_t)s_local), rec->rng_index};
-        for (int bounce = first_bounce; bounce < max_depth; ++bounce) {
-            set_inverse(r);
-            Best b;
-            b.t = D_INF; b.ref = RT_REF_NONE; b.ctx = 0;
-            UvTrack uvt;
-            uvt.ref = RT_REF_NONE; uvt.ctx = 0; uvt.t = 0.0; uvt.any = false;
-            traverse<MEDIA, false, true, true, false, UV>(S, S.world, r, 0, w, time, 0.001, b, stk, 0, &g, nn, np, false, &uvt); // Interval::new(0.001, INFINITY) (camera.rs:258)
-            ++traced;
-            if (b.ref == RT_REF_NONE) { // camera.rs:258-260
-                L = L + beta * d3p(cam.background);
-                break;
-            }
-            HitRec h;
-            finalize(S, r, time, b, h, TEXTURES && S.uses_uv != 0u);
-            if (UV && (b.ref >> 28) == RT_REF_MEDIUM) stale_uv(S, w, time, uvt, h.u, h.v);
-            D3 ray_dir = d3(r.dx, r.dy, r.dz);
-            D3 nd;
-            if (!shade_hit<TEXTURES, RR>(S, h, ray_dir, g, beta, L, nd)) break;
-            if (bounce == max_depth - 1) { // the next ray_color call has depth 0 and returns black (camera.rs:252-254)
-                L = L + beta * d3(0.0, 0.0, 0.0);
-                break;
-            }
-            r.ox = h.p.x; r.oy = h.p.y; r.oz = h.p.z;
-            r.dx = nd.x; r.dy = nd.y; r.dz = nd.z;
-            rec->o[0] = h.p.x; rec->o[1] = h.p.y; rec->o[2] = h.p.z;
-            rec->d[0] = nd.x; rec->d[1] = nd.y; rec->d[2] = nd.z;
-        }
-        rec->L[0] = L.x; rec->L[1] = L.y; rec->L[2] = L.z;
-    }
-    // extend queries of this launch, for the counter the separate launches keep in advance_kernel
-    for (int o = 32; o > 0; o >>= 1) traced += (unsigned long long)__shfl_xor((long long)traced, o);
-    if ((threadIdx.x & 63u) == 0u && traced) atomicAdd(&ps.counters[C_RAYS], traced);
-}
-
-__global__ __launch_bounds__(BLOCK) void accumulate_kernel(PathState ps, BatchGeom bg, double* accum, int32_t image_width) {
-    uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pix >= bg.npix) return;
-    int32_t i = bg.x0 + (int32_t)(pix % (uint32_t)bg.tw);
-    int32_t j = bg.y0 + (int32_t)(pix / (uint32_t)bg.tw);
-    double* a = accum + ((size_t)j * (size_t)image_width + (size_t)i) * 3;
-    double r = a[0], g = a[1], b = a[2];
-    for (int32_t s = 0; s < bg.nsamples; ++s) { // pixel_color += ray_color(...) in stratum order
-        size_t p = (size_t)s * bg.npix + pix;
-        const PathRec* rec = ps.rec + p;
-        r += rec->L[0]; g += rec->L[1]; b += rec->L[2];
-    }
-    a[0] = r; a[1] = g; a[2] = b;
-}
-
 } // namespace
 
 // ============================================================================ host code
-// Measurement switches, read from the environment ONCE, when a scene is created (never per launch).
-struct Tuning {
-    int refill = -1, vote = -1, chunk = 0; // primitive-BVH kernel scheduling (MI355RT_REFILL, MI355RT_VOTE, MI355RT_CHUNK; -1 / 0: the defaults of bvh_kernel.h)
-    int prep_refill = PREP_REFILL_THRESHOLD, prep_vote = PREP_LEAF_VOTE;               // the same for reordered batches
-    bool quant = true;           // MI355RT_QUANT=0: keep the f32 4-wide nodes
-    int postpone = -1;           // MI355RT_POSTPONE=0/1: overrides the choice made from the tree (postponed primitive tests)
-    bool packed = true;          // MI355RT_PACKED=0: keep the 64-byte 8-bit nodes where the 48-byte packed tree exists
-    bool fast_extend = true;     // MI355RT_FAST_EXTEND=0: the renderer keeps the general traversal
-    bool shade_textures = false; // MI355RT_SHADE_TEXTURES=1: always the full shading kernel
-    int reorder = 1;             // MI355RT_REORDER: binning pass in front of large closest-hit batches: 0 never, 1 where it pays (below), 2 always
-    bool debug = false;          // MI355RT_DEBUG: diagnostics on stderr
-    uint64_t device_bvh_min = 1ull << 15; // MI355RT_DEVICE_BVH_MIN: BVHs over at least this many objects are built on the device (0 = never)
-    int fast_blocks_per_cu = 0;  // MI355RT_FAST_BLOCKS_PER_CU: cap on the primitive-BVH kernel's workgroups per CU (occupancy experiments)
-    uint64_t reorder_min = 1ull << 18; // smallest batch that is binned
-    uint64_t tail_paths = 1ull << 16;
-    uint64_t max_paths = 1ull << 27;
-};
-
-constexpr int HIT_RING = 32;
-
-struct rt_scene {
-    FlatScene flat;
-    DScene dev{};
-    bool host_only = false;
-    int device = -1;
-    std::vector<void*> allocs;
-    uint64_t device_bytes = 0;
-    unsigned long long* d_counters = nullptr;
-    unsigned long long* h_counters = nullptr; // pinned
-    // HIP events of the closest-hit calls since the counters were last read: a ring of HIT_RING launches, each with
-    // {call start, traversal start, traversal end, call end}, harvested by rt_get_counters
-    hipEvent_t ev_hit[HIT_RING][4] = {};
-    bool hit_reordered_at[HIT_RING] = {};
-    uint64_t hit_launches = 0, hit_harvested = 0;
-    hipEvent_t ev_r0 = nullptr, ev_r1 = nullptr;
-    bool render_timed = false;
-    rt_counters counters{};
-    int grid_blocks = 0;
-    int fast_grid_blocks = 0;
-    int fast_grid_blocks_prep = 0; // the same for launches on prepared rays (reorder.h), whose kernel variant fits more waves
-    int extend_blocks = 0, shade_blocks = 0, tail_blocks = 0;
-    size_t fast_lds = 0;
-    uint2* fast_spill = nullptr; // HBM overflow of the per-lane stacks: [entry][thread]
-    int32_t* hit_ctx = nullptr;  // transform context of every hit of the current general closest-hit batch
-    uint64_t hit_ctx_cap = 0;
-    int fast_prim = 0;           // leaf kind of the primitive BVH when uniform, else 0
-    int fast_fmt = NODES_F32;    // node records the primitive-BVH kernel reads (bvh_kernel.h)
-    uint32_t fast_entry = RT_REF_NONE; // its root in that format
-    float fast_extent = 0.0f; // largest |coordinate| stored in the 4-wide nodes (error bound of the f32 slab test)
-    // render workspace
-    PathState ps{};
-    uint64_t ws_paths = 0;
-    std::vector<void*> ws_allocs;
-    // reorder pass in front of the primitive-BVH kernel (reorder.h): prepared records in bin order, the bin of every
-    // ray, histogram and bin cursors; grown to the largest batch seen
-    PRay* prep = nullptr;
-    uint16_t* prep_bins = nullptr;
-    uint32_t* prep_hist = nullptr;   // REORDER_BINS words, zero between batches
-    uint32_t* prep_cursor = nullptr; // REORDER_BINS words
-    uint64_t prep_cap = 0;
-    ReorderGrid grid{};
-    Tuning tune;
-};
-
 namespace {
 
 thread_local std::string g_err;
@@ -631,6 +111,26 @@ int set_err(int code, const std::string& m) { g_err = m; return code; }
         if (e_ != hipSuccess)                                                                      \
             return set_err(RT_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));           \
     } while (0)
+
+// One call on a scene at a time (see rt_scene::call_mutex).  begin() makes the call's stream wait for the previous
+// call's work, end() marks the end of this call's work.  `chain` = false for the allocation-free entry point, which
+// may run under graph capture (an event of another stream cannot be waited for there) and documents that
+// overlapping calls race.
+struct SceneCall {
+    rt_scene* s;
+    hipStream_t st;
+    bool chain;
+    std::unique_lock<std::mutex> lock;
+    SceneCall(rt_scene* scene, hipStream_t stream, bool chain_) : s(scene), st(stream), chain(chain_), lock(scene->call_mutex) {}
+    int begin() {
+        if (chain && s->have_done && s->done_stream != st) HIP_TRY(hipStreamWaitEvent(st, s->ev_done, 0));
+        return RT_OK;
+    }
+    int end() {
+        if (chain) { HIP_TRY(hipEventRecord(s->ev_done, st)); s->have_done = true; s->done_stream = st; }
+        return RT_OK;
+    }
+};
 
 // Device address of `scratch` on every GPU the library has set up a scene on.  Each GPU holds its own copy of the
 // array at its own address, so the address is resolved once per device, with that device current.
@@ -689,8 +189,8 @@ Tuning read_tuning() {
     t.chunk = env_int("MI355RT_CHUNK", t.chunk);
     t.packed = env_int("MI355RT_PACKED", 1) != 0;
     t.postpone = env_int("MI355RT_POSTPONE", -1);
-    t.prep_refill = env_int("MI355RT_PREP_REFILL", t.prep_refill);
-    t.prep_vote = env_int("MI355RT_PREP_VOTE", t.prep_vote);
+    t.prep_refill = env_int("MI355RT_PREP_REFILL", PREP_REFILL_THRESHOLD);
+    t.prep_vote = env_int("MI355RT_PREP_VOTE", PREP_LEAF_VOTE);
     t.quant = env_int("MI355RT_QUANT", 1) != 0;
     t.fast_extend = env_int("MI355RT_FAST_EXTEND", 1) != 0;
     t.shade_textures = env_int("MI355RT_SHADE_TEXTURES", 0) != 0;
@@ -714,24 +214,18 @@ int pick_grid(rt_scene* s) {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, s->device));
     int per_cu = 0;
-    if (s->flat.medium_depth > 1) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, closest_hit_kernel<false, true, 2>, BLOCK, 0));
-    else if (s->flat.has_medium) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, closest_hit_kernel<false, true, 1>, BLOCK, 0));
+    const int media = s->flat.medium_depth > 1 ? 2 : (s->flat.has_medium ? 1 : 0);
+    if (media > 1) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, closest_hit_kernel<false, true, 2>, BLOCK, 0));
+    else if (media) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, closest_hit_kernel<false, true, 1>, BLOCK, 0));
     else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, closest_hit_kernel<false, true, false>, BLOCK, 0));
-    int per_cu2 = 0;
-    if (s->flat.medium_depth > 1) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, extend_kernel<2>, BLOCK, 0));
-    else if (s->flat.has_medium) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, extend_kernel<1>, BLOCK, 0));
-    else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, extend_kernel<false>, BLOCK, 0));
-    int per_cu3 = 0;
+    int per_cu2 = 0, per_cu3 = 0, per_cu4 = 0;
     // (grids are sized for the variants without the roulette rule; a render with the rule runs on the same grid)
-    if (s->flat.has_textures) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu3, shade_kernel<true, false>, BLOCK, 0));
-    else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu3, shade_kernel<false, false>, BLOCK, 0));
+    HIP_TRY(occupancy_extend(media, &per_cu2));
+    HIP_TRY(occupancy_shade(s->flat.has_textures, &per_cu3));
+    HIP_TRY(occupancy_tail(media, &per_cu4));
     s->grid_blocks = prop.multiProcessorCount * std::max(1, per_cu);      // batched closest hit (general kernel)
     s->extend_blocks = prop.multiProcessorCount * std::max(1, per_cu2);   // each kernel fills the chip at its own occupancy
     s->shade_blocks = prop.multiProcessorCount * std::max(1, per_cu3);
-    int per_cu4 = 0;
-    if (s->flat.medium_depth > 1) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu4, tail_kernel<2, true, false>, BLOCK, 0));
-    else if (s->flat.has_medium) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu4, tail_kernel<1, true, false>, BLOCK, 0));
-    else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu4, tail_kernel<false, true, false>, BLOCK, 0));
     s->tail_blocks = prop.multiProcessorCount * std::max(1, per_cu4);
     if (s->flat.fast_root != RT_REF_NONE) {
         s->fast_lds = 0;
@@ -827,6 +321,7 @@ int upload_scene(rt_scene* s) {
         for (int e = 0; e < 4; ++e) HIP_TRY(hipEventCreate(&s->ev_hit[k][e]));
     HIP_TRY(hipEventCreate(&s->ev_r0));
     HIP_TRY(hipEventCreate(&s->ev_r1));
+    HIP_TRY(hipEventCreateWithFlags(&s->ev_done, hipEventDisableTiming));
     {   // grid of the reorder pass: 16 cells per axis over the world's box (a degenerate or unbounded axis gets one cell)
         const double* wb = s->flat.world_bounds.b;
         for (int k = 0; k < 3; ++k) {
@@ -887,6 +382,17 @@ int ensure_reorder_scratch(rt_scene* s, uint64_t n) {
     return RT_OK;
 }
 
+int ensure_hit_ctx(rt_scene* s, uint64_t n) { // scratch between the traversal and the record-completion pass, grown to the largest batch seen
+    if (s->hit_ctx_cap >= n) return RT_OK;
+    if (s->hit_ctx) (void)hipFree(s->hit_ctx);
+    s->hit_ctx = nullptr; s->hit_ctx_cap = 0;
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, n * sizeof(int32_t)));
+    s->hit_ctx = static_cast<int32_t*>(p);
+    s->hit_ctx_cap = n;
+    return RT_OK;
+}
+
 // ctx_scratch: where the general kernels keep the transform context of every hit between traversal and record
 // completion (n words); nullptr = the scene's own buffer, grown with hipMalloc to the largest batch seen.
 int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit_batch* hits, uint64_t seed, uint32_t flags, hipStream_t st,
@@ -897,7 +403,11 @@ int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit
     uint64_t waves = (n + 63) / 64;
     int blocks = (int)std::min<uint64_t>((uint64_t)s->grid_blocks, (waves + (BLOCK / 64) - 1) / (BLOCK / 64));
     hipEvent_t* const ev = s->ev_hit[s->hit_launches % HIT_RING]; // start, traversal start, traversal end, end
-    HIP_TRY(hipEventRecord(ev[0], st));
+    // The allocation-free entry point (ctx_scratch given) records no timing events and leaves the ring alone: on a
+    // capturing stream an event record is a graph node, not a timestamp, and rt_get_counters could not read it back.
+    const bool timed = ctx_scratch == nullptr;
+#define RT_EVENT(e_) do { if (timed) HIP_TRY(hipEventRecord((e_), st)); } while (0)
+    RT_EVENT(ev[0]);
     // RT_HIT_ORDERED | RT_HIT_EXACT_CULL: the exact binary nodes, children ordered by the split axis (general kernel)
     const bool exact_cull = (flags & RT_HIT_ORDERED) && (flags & RT_HIT_EXACT_CULL);
     const bool count = flags & RT_HIT_COUNTERS, ordered = (flags & RT_HIT_ORDERED) && !exact_cull;
@@ -921,6 +431,9 @@ int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit
             int rc = ensure_reorder_scratch(s, n);
             if (rc) return rc;
             const int cblocks = (int)std::min<uint64_t>(2048, (n + REORDER_BLOCK - 1) / REORDER_BLOCK);
+            // (the scan pass leaves the histogram cleared; clearing it here as well costs 16 KiB and makes a batch
+            // independent of how the previous one ended)
+            HIP_TRY(hipMemsetAsync(s->prep_hist, 0, REORDER_BINS * sizeof(uint32_t), st));
             hipLaunchKernelGGL(reorder_count_kernel, dim3(cblocks), dim3(REORDER_BLOCK), 0, st, *rays, (unsigned long long)n, s->grid, s->prep_bins, s->prep_hist);
             hipLaunchKernelGGL(reorder_scan_kernel, dim3(1), dim3(1024), 0, st, s->prep_hist, s->prep_cursor);
             // (the packed tree takes 64-byte records; it is not used when the batch brings lower ends of its own, see below)
@@ -929,7 +442,7 @@ int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit
                                (unsigned long long)n, opt, 0.001, s->fast_extent, (const uint16_t*)s->prep_bins, s->prep_cursor, s->prep);
             HIP_TRY(hipGetLastError());
         }
-        HIP_TRY(hipEventRecord(ev[1], st));
+        RT_EVENT(ev[1]);
         // the packed nodes order children by keys that need entry distances >= 0, i.e. tmin >= 0: certain only for the default tmin
         const int fmt = (s->fast_fmt == NODES_PACKED && (opt & 2u)) ? NODES_8BIT : s->fast_fmt;
         const uint32_t entry = fmt == s->fast_fmt ? s->fast_entry : s->flat.fast_root;
@@ -950,24 +463,16 @@ int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit
                            s->fast_extent, hits->t, hits->prim, s->d_counters + C_WORK_SLOTS, s->d_counters + C_NODES, s->fast_spill,
                            refill, vote, tn.chunk, postpone, (const PRay*)s->prep);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(ev[2], st));
+        RT_EVENT(ev[2]);
         if (hits->u || hits->v || hits->front_face || hits->mat || hits->nx || hits->ny || hits->nz || hits->px || hits->py || hits->pz)
             hipLaunchKernelGGL(finalize_hits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s->dev, *rays, (unsigned long long)n, *hits, (const int32_t*)nullptr, 0);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(ev[3], st)); // the whole call: reorder pass, traversal, record completion
-        s->hit_reordered_at[s->hit_launches % HIT_RING] = reorder;
-        ++s->hit_launches;
+        RT_EVENT(ev[3]); // the whole call: reorder pass, traversal, record completion
+        if (timed) { s->hit_reordered_at[s->hit_launches % HIT_RING] = reorder; ++s->hit_launches; }
         s->counters.rays += n;
         return RT_OK;
     }
-    if (!ctx_scratch && s->hit_ctx_cap < n) { // scratch between the traversal and the record-completion pass, grown to the largest batch seen
-        if (s->hit_ctx) (void)hipFree(s->hit_ctx);
-        s->hit_ctx = nullptr; s->hit_ctx_cap = 0;
-        void* p = nullptr;
-        HIP_TRY(hipMalloc(&p, n * sizeof(int32_t)));
-        s->hit_ctx = static_cast<int32_t*>(p);
-        s->hit_ctx_cap = n;
-    }
+    if (!ctx_scratch) { int rcc = ensure_hit_ctx(s, n); if (rcc) return rcc; }
     int32_t* const hit_ctx = ctx_scratch ? ctx_scratch : s->hit_ctx;
     // ordered traversal of a world whose first member has a primitive BVH of its own: that member through the
     // primitive-BVH kernel, the rest through the general one, which starts from the first member's closest hit
@@ -982,7 +487,7 @@ int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemsetAsync(s->d_counters + C_WORK_SLOTS, 0, WORK_SLOTS * WORK_STRIDE * sizeof(unsigned long long), st));
     }
-    HIP_TRY(hipEventRecord(ev[1], st));
+    RT_EVENT(ev[1]);
     auto launch = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3(blocks), dim3(BLOCK), 0, st, s->dev, *rays, (unsigned long long)n, *hits, hit_ctx, (unsigned long long)seed, s->d_counters,
                            split ? 1 : 0, exact_cull ? 1 : 0);
@@ -1008,12 +513,12 @@ int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit
         else if (ordered) launch(closest_hit_kernel<false, true, 0>);
         else launch(closest_hit_kernel<false, false, 0>);
     }
-    HIP_TRY(hipEventRecord(ev[2], st));
+    RT_EVENT(ev[2]);
     hipLaunchKernelGGL(finalize_hits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s->dev, *rays, (unsigned long long)n, *hits, (const int32_t*)hit_ctx, s->flat.track_uv ? 1 : 0);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(ev[3], st));
-    s->hit_reordered_at[s->hit_launches % HIT_RING] = false;
-    ++s->hit_launches;
+    RT_EVENT(ev[3]);
+#undef RT_EVENT
+    if (timed) { s->hit_reordered_at[s->hit_launches % HIT_RING] = false; ++s->hit_launches; }
     s->counters.rays += n;
     return RT_OK;
 }
@@ -1054,8 +559,8 @@ int render_impl(rt_scene* s, const rt_camera* cam, uint64_t seed, const rt_work*
             bg.sample0 = s0; bg.nsamples = std::min(samples_per_batch, w.sample_end - s0);
             bg.npix = (uint32_t)tw * (uint32_t)th;
             bg.npaths = bg.npix * (uint32_t)bg.nsamples;
-            hipLaunchKernelGGL(init_batch_kernel, dim3(1), dim3(1), 0, st, s->d_counters, (unsigned long long)bg.npaths);
-            hipLaunchKernelGGL(raygen_kernel, dim3((bg.npaths + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, cd, bg, ps, (unsigned long long)seed);
+            launch_init_batch(st, s->d_counters, (unsigned long long)bg.npaths);
+            launch_raygen(st, cd, bg, ps, (unsigned long long)seed);
             s->counters.paths += bg.npaths;
             int qsel = 0;
             uint64_t live = bg.npaths;
@@ -1071,14 +576,7 @@ int render_impl(rt_scene* s, const rt_camera* cam, uint64_t seed, const rt_work*
                 if (live_exact && bounce > 0 && live <= tail_paths) {
                     // few paths left: they finish in one launch, each lane following its path to the end
                     const int tblocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)s->tail_blocks, (live + BLOCK - 1) / BLOCK));
-                    // (nested media: the full shading code whatever the textures, to keep the number of variants down)
-                    auto tail = s->flat.track_uv ? (rr ? tail_kernel<2, true, true, true> : tail_kernel<2, true, false, true>)
-                              : media == 2 ? (rr ? tail_kernel<2, true, true> : tail_kernel<2, true, false>)
-                              : rr ? (media ? (has_tex ? tail_kernel<1, true, true> : tail_kernel<1, false, true>)
-                                            : (has_tex ? tail_kernel<0, true, true> : tail_kernel<0, false, true>))
-                                   : (media ? (has_tex ? tail_kernel<1, true, false> : tail_kernel<1, false, false>)
-                                            : (has_tex ? tail_kernel<0, true, false> : tail_kernel<0, false, false>));
-                    hipLaunchKernelGGL(tail, dim3(tblocks), dim3(BLOCK), 0, st, s->dev, cd, ps, qsel, (unsigned long long)seed, bg, (int)bounce, (int)cam->max_depth);
+                    launch_tail(st, tblocks, media, has_tex, rr, s->flat.track_uv, s->dev, cd, ps, qsel, (unsigned long long)seed, bg, (int)bounce, (int)cam->max_depth);
                     s->counters.extend_launches += 1;
                     break;
                 }
@@ -1102,14 +600,11 @@ int render_impl(rt_scene* s, const rt_camera* cam, uint64_t seed, const rt_work*
                                        s->d_counters + C_NODES, s->fast_spill, k_refill, k_vote, k_chunk, 0, (const PRay*)nullptr);
                 }
                 if (!fast_extend || s->flat.fast_partial) { // the whole world, or what follows its first member
-                    if (fast_extend) hipLaunchKernelGGL(reset_work_kernel, dim3(1), dim3(1), 0, st, s->d_counters);
-                    auto extend = media == 2 ? extend_kernel<2> : (media ? extend_kernel<1> : extend_kernel<0>);
-                    if (s->flat.track_uv) extend = extend_kernel<2, true>;
-                    hipLaunchKernelGGL(extend, dim3(blocks), dim3(BLOCK), 0, st, s->dev, ps, qsel,
-                                       (unsigned long long)seed, bg, cam->image_width, fast_extend ? 1 : 0);
+                    if (fast_extend) launch_reset_work(st, s->d_counters);
+                    launch_extend(st, blocks, media, s->flat.track_uv, s->dev, ps, qsel, (unsigned long long)seed, bg, cam->image_width, fast_extend ? 1 : 0);
                 }
-                hipLaunchKernelGGL(rr ? (has_tex ? shade_kernel<true, true> : shade_kernel<false, true>) : (has_tex ? shade_kernel<true, false> : shade_kernel<false, false>), dim3(sblocks), dim3(BLOCK), 0, st, s->dev, cd, ps, qsel, (unsigned long long)seed, bg, bounce == cam->max_depth - 1 ? 1 : 0);
-                hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, st, s->d_counters);
+                launch_shade(st, sblocks, has_tex, rr, s->dev, cd, ps, qsel, (unsigned long long)seed, bg, bounce == cam->max_depth - 1 ? 1 : 0);
+                launch_advance(st, s->d_counters);
                 s->counters.extend_launches += 1;
                 qsel ^= 1;
                 // `live` only sizes the next launches and ends a dead batch early (the kernels read the exact count
@@ -1123,7 +618,7 @@ int render_impl(rt_scene* s, const rt_camera* cam, uint64_t seed, const rt_work*
                     live_exact = true;
                 }
             }
-            hipLaunchKernelGGL(accumulate_kernel, dim3((bg.npix + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, ps, bg, d_accum, cam->image_width);
+            launch_accumulate(st, ps, bg, d_accum, cam->image_width);
             HIP_TRY(hipGetLastError());
         }
     }
@@ -1187,6 +682,7 @@ int rt_scene_destroy(rt_scene* s) {
             for (int e = 0; e < 4; ++e) if (s->ev_hit[k][e]) (void)hipEventDestroy(s->ev_hit[k][e]);
         if (s->ev_r0) (void)hipEventDestroy(s->ev_r0);
         if (s->ev_r1) (void)hipEventDestroy(s->ev_r1);
+        if (s->ev_done) (void)hipEventDestroy(s->ev_done);
     }
     delete s;
     return RT_OK;
@@ -1296,13 +792,32 @@ int rt_scene_object_bounds(const rt_scene* s, int32_t object, double out[6]) {
     return RT_OK;
 }
 
+int rt_scene_reserve(rt_scene* s, uint64_t max_rays, uint64_t max_paths) {
+    int rc = need_device(s);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(s->call_mutex);
+    HIP_TRY(hipDeviceSynchronize()); // buffers in use by calls still in flight are about to be replaced
+    if (max_rays) {
+        const bool fast_whole = s->flat.fast_root != RT_REF_NONE && !s->flat.fast_partial;
+        if (fast_whole && max_rays <= 0xFFFFFFFFull && (rc = ensure_reorder_scratch(s, max_rays))) return rc;
+        if ((rc = ensure_hit_ctx(s, max_rays))) return rc;
+    }
+    if (max_paths) {
+        if ((rc = ensure_workspace(s, std::min<uint64_t>(max_paths, s->tune.max_paths)))) return rc;
+    }
+    return RT_OK;
+}
+
 int rt_closest_hit_device(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit_batch* hits, uint64_t seed, uint32_t flags, void* hip_stream) {
     int rc = need_device(s);
     if (rc) return rc;
     if (!rays || !hits) return set_err(RT_E_INVALID, "rt_closest_hit_device: null batch");
     if (n && (!rays->ox || !rays->oy || !rays->oz || !rays->dx || !rays->dy || !rays->dz || !hits->t || !hits->prim))
         return set_err(RT_E_INVALID, "rt_closest_hit_device: origin, direction, t and prim arrays are required");
-    return launch_closest_hit(s, rays, n, hits, seed, flags, static_cast<hipStream_t>(hip_stream));
+    SceneCall call(s, static_cast<hipStream_t>(hip_stream), true);
+    if ((rc = call.begin())) return rc;
+    if ((rc = launch_closest_hit(s, rays, n, hits, seed, flags, call.st))) return rc;
+    return call.end();
 }
 
 int rt_closest_hit_device_noalloc(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit_batch* hits, uint64_t seed, uint32_t flags, void* hip_stream) {
@@ -1315,7 +830,8 @@ int rt_closest_hit_device_noalloc(rt_scene* s, const rt_ray_batch* rays, uint64_
         return set_err(RT_E_TOO_LARGE, "rt_closest_hit_device_noalloc: at most 16777216 (2^24) rays per call; split the batch or use rt_closest_hit_device");
     int32_t* const ptr = (s->device >= 0 && s->device < NOALLOC_MAX_DEVICES) ? g_scratch_ptr[s->device] : nullptr;
     if (!ptr) return set_err(RT_E_HIP, "rt_closest_hit_device_noalloc: the scratch array of this device was not resolved at scene creation");
-    return launch_closest_hit(s, rays, n, hits, seed, flags, static_cast<hipStream_t>(hip_stream), ptr);
+    SceneCall call(s, static_cast<hipStream_t>(hip_stream), false); // host-side state only: see SceneCall
+    return launch_closest_hit(s, rays, n, hits, seed, flags, call.st, ptr);
 }
 
 int rt_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit_batch* hits, uint64_t seed, uint32_t flags) {
@@ -1325,6 +841,8 @@ int rt_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit_bat
     if (n == 0) return RT_OK;
     if (!rays->ox || !rays->oy || !rays->oz || !rays->dx || !rays->dy || !rays->dz || !hits->t || !hits->prim)
         return set_err(RT_E_INVALID, "rt_closest_hit: origin, direction, t and prim arrays are required");
+    SceneCall call(s, nullptr, true); // held to the end: the call waits for its results
+    if ((rc = call.begin())) return rc;
     std::vector<void*> tmp;
     auto cleanup = [&]() { for (void* p : tmp) (void)hipFree(p); };
     auto to_dev = [&](const void* h, size_t bytes, const void** d) -> int {
@@ -1372,7 +890,7 @@ int rt_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit_bat
     if ((rc = back(hits->front_face, dh.front_face, n * sizeof(uint8_t)))) { cleanup(); return rc; }
     if ((rc = back(hits->mat, dh.mat, n * sizeof(int32_t)))) { cleanup(); return rc; }
     cleanup();
-    return RT_OK;
+    return call.end();
 }
 
 int rt_camera_initialize(const rt_camera* cam, rt_camera_derived* out) {
@@ -1385,7 +903,10 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, uint64_t seed, const rt_
     int rc = need_device(s);
     if (rc) return rc;
     if (!cam || !accum) return set_err(RT_E_INVALID, "rt_render_device: null argument");
-    return render_impl(s, cam, seed, work, accum, static_cast<hipStream_t>(hip_stream));
+    SceneCall call(s, static_cast<hipStream_t>(hip_stream), true);
+    if ((rc = call.begin())) return rc;
+    if ((rc = render_impl(s, cam, seed, work, accum, call.st))) return rc;
+    return call.end();
 }
 
 int rt_render(rt_scene* s, const rt_camera* cam, uint64_t seed, const rt_work* work, double* accum) {
@@ -1396,6 +917,8 @@ int rt_render(rt_scene* s, const rt_camera* cam, uint64_t seed, const rt_work* w
     std::string err;
     if ((rc = camera_initialize(cam, &d, err))) return set_err(rc, err);
     size_t bytes = (size_t)cam->image_width * (size_t)d.image_height * 3 * sizeof(double);
+    SceneCall call(s, nullptr, true);
+    if ((rc = call.begin())) return rc;
     double* dacc = nullptr;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dacc), bytes));
     hipError_t e = hipMemcpy(dacc, accum, bytes, hipMemcpyHostToDevice);
@@ -1409,7 +932,7 @@ int rt_render(rt_scene* s, const rt_camera* cam, uint64_t seed, const rt_work* w
     (void)hipFree(dacc);
     if (rc) return rc;
     if (e != hipSuccess) return set_err(RT_E_HIP, std::string("rt_render: ") + hipGetErrorString(e));
-    return RT_OK;
+    return call.end();
 }
 
 int rt_resolve_rgb8(const rt_camera* cam, const double* accum, uint8_t* rgb) { // camera.rs:133-135, color.rs:58-80
@@ -1442,12 +965,14 @@ int rt_write_ppm(const char* path, int32_t width, int32_t height, const uint8_t*
 
 int rt_get_counters(rt_scene* s, rt_counters* out) {
     if (!s || !out) return set_err(RT_E_INVALID, "rt_get_counters: null argument");
+    std::lock_guard<std::mutex> lock(s->call_mutex);
     if (!s->host_only) {
         HIP_TRY(hipSetDevice(s->device));
         HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(hipMemcpy(s->h_counters, s->d_counters, C_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         s->counters.node_visits = s->h_counters[C_NODES];
         s->counters.prim_tests = s->h_counters[C_PRIMS];
+        if (s->h_counters[C_NODES + 20]) s->counters.shader_khz = s->h_counters[C_NODES + 20];
         // closest-hit calls since the last harvest (at most the HIT_RING newest still have their events)
         if (s->hit_launches - s->hit_harvested > (uint64_t)HIT_RING) s->hit_harvested = s->hit_launches - HIT_RING;
         for (; s->hit_harvested < s->hit_launches; ++s->hit_harvested) {
@@ -1487,6 +1012,7 @@ int rt_get_counters(rt_scene* s, rt_counters* out) {
 
 int rt_reset_counters(rt_scene* s) {
     if (!s) return set_err(RT_E_INVALID, "rt_reset_counters: null scene");
+    std::lock_guard<std::mutex> lock(s->call_mutex);
     s->counters = rt_counters{};
     s->hit_harvested = s->hit_launches;
     if (!s->host_only) {

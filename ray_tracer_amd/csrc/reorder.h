@@ -82,6 +82,7 @@ RT_DEV uint32_t ray_bin(const ReorderGrid& g, double ox, double oy, double oz) {
     return key;
 }
 
+#ifdef RT_REORDER_KERNELS // the kernels are compiled into the translation unit that launches them (mi355rt.hip)
 // Pass 1: bin of every ray (kept for pass 2) and the batch's histogram.
 __global__ __launch_bounds__(REORDER_BLOCK) void reorder_count_kernel(rt_ray_batch rays, unsigned long long n, ReorderGrid g, uint16_t* bins, uint32_t* hist) {
     __shared__ uint32_t s_hist[REORDER_BINS];
@@ -207,6 +208,8 @@ __global__ __launch_bounds__(SCATTER_BLOCK) void reorder_scatter_kernel(rt_ray_b
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
 }
+
+#endif // RT_REORDER_KERNELS
 
 } // namespace rt
 #endif

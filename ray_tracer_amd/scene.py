@@ -323,6 +323,10 @@ class Scene:
         fn = F.lib.rt_closest_hit_device_noalloc if noalloc else F.lib.rt_closest_hit_device
         F.check(fn(self._h, C.byref(rb), n, C.byref(hb), seed, flags, C.c_void_p(stream)))
 
+    def reserve(self, max_rays: int = 0, max_paths: int = 0) -> None:
+        """Sizes the scene's device scratch ahead of time, so that later *_device calls within these sizes only enqueue."""
+        F.check(F.lib.rt_scene_reserve(self._h, max_rays, max_paths))
+
     # ------------------------------------------------------------------- render
     def render(self, cam: F.rt_camera, seed: int = 0, work: Optional[F.rt_work] = None,
                accum: Optional[np.ndarray] = None) -> np.ndarray:

@@ -100,8 +100,12 @@ pub struct GpuScene {
     bounds: Aabb,
     pub seed: u64,
 }
+// The handle may be used from every rayon worker at once, as the reference uses `world` (camera.rs:99): the library
+// holds a mutex of the scene while a call enqueues (to the end of the call for the host-pointer entry points, which
+// wait for their results) and orders calls on different streams on the device (mi355rt.h, "Threads and streams").
+// `rt_last_error` is thread-local.  Nothing behind the handle is reachable from Rust except through those calls.
 unsafe impl Send for GpuScene {}
-unsafe impl Sync for GpuScene {} // the library serialises nothing: callers keep one call in flight per scene
+unsafe impl Sync for GpuScene {}
 
 impl GpuScene {
     pub fn new(world: &dyn Describe, lights: Option<&dyn Describe>) -> Result<Self, RtError> {

@@ -50,7 +50,7 @@ use std::os::raw::{c_char, c_int, c_void};
                                       pub world_ref: u32, pub max_stack: u32, pub device_bytes: u64, pub world_bounds: [f64; 6] }
 #[repr(C)] pub struct rt_counters { pub rays: u64, pub node_visits: u64, pub prim_tests: u64, pub paths: u64, pub render_rays: u64,
                                     pub extend_launches: u64, pub ms_last_closest_hit: f64, pub ms_last_render: f64, pub ms_last_traversal: f64, pub ms_last_reorder: f64,
-                                    pub ms_sum_closest_hit: f64, pub ms_sum_traversal: f64, pub ms_sum_reorder: f64, pub timed_calls: u64 }
+                                    pub ms_sum_closest_hit: f64, pub ms_sum_traversal: f64, pub ms_sum_reorder: f64, pub timed_calls: u64, pub shader_khz: u64 }
 
 #[link(name = "mi355rt")]
 extern "C" {
@@ -66,6 +66,7 @@ extern "C" {
     pub fn rt_obj_load(path: *const c_char, scale_offset: *const f64, mat: i32, triangles: *mut *mut rt_triangle, n_triangles: *mut u64) -> c_int;
     pub fn rt_obj_free(triangles: *mut rt_triangle);
     pub fn rt_closest_hit(scene: *mut rt_scene, rays: *const rt_ray_batch, n: u64, hits: *mut rt_hit_batch, seed: u64, flags: u32) -> c_int;
+    pub fn rt_scene_reserve(scene: *mut rt_scene, max_rays: u64, max_paths: u64) -> c_int;
     pub fn rt_closest_hit_device(scene: *mut rt_scene, rays: *const rt_ray_batch, n: u64, hits: *mut rt_hit_batch, seed: u64, flags: u32, stream: *mut c_void) -> c_int;
     pub fn rt_closest_hit_device_noalloc(scene: *mut rt_scene, rays: *const rt_ray_batch, n: u64, hits: *mut rt_hit_batch, seed: u64, flags: u32, stream: *mut c_void) -> c_int;
     pub fn rt_camera_initialize(cam: *const rt_camera, out: *mut rt_camera_derived) -> c_int;

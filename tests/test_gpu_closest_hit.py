@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 EXACT = ("t", "prim", "front_face", "mat", "nx", "ny", "nz", "px", "py", "pz")
 
 
-def compare(desc, o, d, time=None, tmin=None, tmax=None, seed=0, min_hits=1, flags=0, medium_uv=False):
+def compare(desc, o, d, time=None, tmin=None, tmax=None, seed=0, min_hits=1, flags=0, medium_uv=False, max_ties=0.02):
     gpu = rt.Scene(desc)
     cpu = O.OracleScene(desc)
     a = gpu.closest_hit(o, d, time=time, tmin=tmin, tmax=tmax, seed=seed, flags=flags)
@@ -31,7 +31,7 @@ def compare(desc, o, d, time=None, tmin=None, tmax=None, seed=0, min_hits=1, fla
         # at exactly that t another one of them may be reported (bar: ties within 1e-6 relative)
         tie = (a["prim"] != b["prim"])
         assert np.array_equal(a["t"][tie & ~medium], b["t"][tie & ~medium])
-        assert tie.mean() < 0.02, tie.mean()
+        assert tie.mean() < max_ties, tie.mean()
         for f in a:
             a[f] = a[f][~tie]; b[f] = b[f][~tie]
         medium = medium[~tie]
@@ -553,3 +553,110 @@ def test_obj_file_to_gpu(tmp_path):
     world = rt.HittableList.with_object(rt.Translate(rt.RotateY(mesh, 30.0), rt.Vec3(0.5, 0.0, 0.0)))
     world.add(rt.Sphere(rt.Point3(0.0, -101.5, 0.0), 100.0, rt.Lambertian(rt.Color(.5, .5, .5))))
     compare(rt.SceneDesc.from_world(world), o, d, min_hits=15000, flags=F.RT_HIT_ORDERED)
+
+
+def test_rays_at_shared_edges_and_vertices_from_far_away(monkeypatch):
+    """Rays aimed exactly at the vertices and edge midpoints of a closed mesh, from origins up to 10^5 scene sizes away:
+    the triangles around a vertex are hit within a few f32 units in the last place of each other (or at the same t), and
+    their boxes are entered at nearly the same distance.  The entry distance a deferred subtree is stored with must
+    stay a lower bound, or the pop-time cull drops the subtree that holds the closer triangle.  Closest t must be the
+    oracle's bit for bit, with batches traced as they come and through the binning pass."""
+    m = rt.Lambertian(rt.Color(.5, .5, .5))
+    tris = scenes.icosphere_mesh(subdiv=4)
+    desc = rt.SceneDesc.from_world(rt.Mesh(tris, m))
+    g = np.random.default_rng(77)
+    verts = tris.reshape(-1, 3)
+    mids = 0.5 * (tris[:, 0] + tris[:, 1])
+    targets = np.concatenate([verts[g.integers(0, len(verts), 6000)], mids[g.integers(0, len(mids), 6000)]])
+    dirs = g.normal(size=targets.shape)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    for pass_on in (False, True):
+        if pass_on:
+            monkeypatch.setenv("MI355RT_REORDER_MIN", "1")
+            monkeypatch.setenv("MI355RT_REORDER", "2")
+        for dist, unit in ((3.0, False), (1e3, True), (1e5, True), (1e5, False)):
+            o = targets - dirs * dist
+            d = dirs if unit else (targets - o)  # unit directions: t ~ dist; unnormalised: t ~ 1
+            # (several triangles meet at every target: exact ties are the rule here, and any of the tied triangles may be reported)
+            compare(desc, o, d, min_hits=6000, flags=F.RT_HIT_ORDERED, max_ties=0.9)
+
+
+def test_one_scene_from_several_threads():
+    """The reference calls world.hit on one world from every rayon worker (camera.rs:99).  Several host threads call
+    rt_closest_hit on ONE scene at once (ctypes releases the interpreter lock during the call): the library puts the
+    calls in a row, and every thread gets the results of a call made alone.  Device-pointer calls on different streams
+    of one scene are ordered on the device the same way."""
+    import threading
+    world, lights, cam = scenes.book2_final(seed=0)
+    desc = rt.SceneDesc.from_world(world, lights)
+    gpu = rt.Scene(desc)
+    batches = [scenes.incoherent_rays(30000, [-200, 600, 0, 560, -200, 600], seed=90 + k) for k in range(4)]
+    alone = [gpu.closest_hit(o, d, time=tm, seed=k, flags=F.RT_HIT_ORDERED) for k, (o, d, tm) in enumerate(batches)]
+    got = [None] * len(batches)
+    errors = []
+
+    def worker(k):
+        try:
+            for _ in range(3):
+                o, d, tm = batches[k]
+                got[k] = gpu.closest_hit(o, d, time=tm, seed=k, flags=F.RT_HIT_ORDERED)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(len(batches))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for a, b in zip(alone, got):
+        for f in a:
+            assert np.array_equal(a[f].view(np.uint8), b[f].view(np.uint8)), f
+    # device pointers, one stream per batch, no host synchronisation between the calls
+    import torch
+    dev = torch.device("cuda", 0)
+    streams = [torch.cuda.Stream(device=dev) for _ in batches]
+    outs = []
+    for k, (o, d, tm) in enumerate(batches):
+        rays = {nm: torch.from_numpy(np.ascontiguousarray(o[:, j])).to(dev) for j, nm in enumerate(("ox", "oy", "oz"))}
+        rays.update({nm: torch.from_numpy(np.ascontiguousarray(d[:, j])).to(dev) for j, nm in enumerate(("dx", "dy", "dz"))})
+        rays["time"] = torch.from_numpy(np.ascontiguousarray(tm)).to(dev)
+        hits = {"t": torch.empty(len(o), dtype=torch.float64, device=dev), "prim": torch.empty(len(o), dtype=torch.int32, device=dev)}
+        outs.append((rays, hits))
+    torch.cuda.synchronize()
+    for k, (rays, hits) in enumerate(outs):
+        gpu.closest_hit_device(rays, hits, len(batches[k][0]), seed=k, flags=F.RT_HIT_ORDERED, stream=streams[k].cuda_stream)
+    torch.cuda.synchronize()
+    for k, (rays, hits) in enumerate(outs):
+        assert np.array_equal(hits["t"].cpu().numpy().view(np.uint64), alone[k]["t"].view(np.uint64))
+        assert np.array_equal(hits["prim"].cpu().numpy().astype(np.uint32), alone[k]["prim"])
+    gpu.close()
+
+
+def test_reserved_scene_allocates_nothing_in_device_calls():
+    """rt_scene_reserve sizes the scratch of the *_device entry points ahead of time: calls within the reserved sizes
+    leave the free device memory as it was (general traversal: 4 bytes per ray; a triangle mesh whose batches are
+    binned: the prepared records)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    m = rt.Lambertian(rt.Color(.5, .5, .5))
+    world, lights, _ = scenes.cornell_box()
+    cases = [(rt.SceneDesc.from_world(world, lights), [1, 554, 1, 554, 1, 554]),
+             (rt.SceneDesc.from_world(rt.Mesh(scenes.triangle_soup(20000, seed=13, edge=0.05), m)), [0, 1, 0, 1, 0, 1])]
+    n = 300000
+    for desc, box in cases:
+        gpu = rt.Scene(desc)
+        o, d, tm = scenes.incoherent_rays(n, box, seed=43)
+        rays = {nm: torch.from_numpy(np.ascontiguousarray(o[:, j])).to(dev) for j, nm in enumerate(("ox", "oy", "oz"))}
+        rays.update({nm: torch.from_numpy(np.ascontiguousarray(d[:, j])).to(dev) for j, nm in enumerate(("dx", "dy", "dz"))})
+        hits = {"t": torch.empty(n, dtype=torch.float64, device=dev), "prim": torch.empty(n, dtype=torch.int32, device=dev),
+                "u": torch.empty(n, dtype=torch.float64, device=dev)}
+        gpu.reserve(max_rays=n)
+        torch.cuda.synchronize()
+        free_before = torch.cuda.mem_get_info(dev)[0]
+        for flags in (F.RT_HIT_REFERENCE_ORDER, F.RT_HIT_ORDERED):
+            gpu.closest_hit_device(rays, hits, n, flags=flags, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert torch.cuda.mem_get_info(dev)[0] == free_before
+        assert int((hits["prim"] != -1).sum().item()) > n // 10
+        gpu.close()

@@ -65,13 +65,19 @@ def _worker(rank, world, port, mode, out_path):
         acc2, tm = parallel.render_frame_job(render_unit, acc2, cam.image_width, d.image_height, d.sqrt_spp * d.sqrt_spp, dist=dist,
                                              mode=mode, strata_limit=5)
         assert tm["world_size"] == world and tm["rank"] == rank and tm["strata"] == 5 and tm["render_s"] >= 0 and tm["reduce_s"] >= 0
+        # the other exchange of each partition: reduce-scatter by band owner + gather for strata, a plain sum for tiles
+        other = "reduce_scatter" if mode == "strata" else "reduce"
+        acc3 = torch.zeros_like(accum)
+        acc3, tm3 = parallel.render_frame_job(render_unit, acc3, cam.image_width, d.image_height, d.sqrt_spp * d.sqrt_spp, dist=dist,
+                                              mode=mode, strata_limit=5, collective=other)
+        assert tm["collective"] == ("reduce" if mode == "strata" else "gather") and tm3["collective"] == other
         counts = [None] * world
         dist.all_gather_object(counts, tm["paths"])
         if rank == 0:
             assert sum(counts) == cam.image_width * d.image_height * 5  # every (pixel, stratum) of the sample exactly once
             full = cpu.render(c, seed=11, nthreads=2)
             part = cpu.render(c, seed=11, work=F.rt_work(0, 0, cam.image_width, d.image_height, 0, 5), nthreads=2)
-            np.save(out_path, np.stack([accum.numpy(), full, acc2.numpy(), part]))
+            np.save(out_path, np.stack([accum.numpy(), full, acc2.numpy(), part, acc3.numpy()]))
     finally:
         dist.destroy_process_group()
 
@@ -81,7 +87,13 @@ def test_two_rank_render_equals_unsplit_frame(tmp_path, mode):
     import torch.multiprocessing as mp
     out = str(tmp_path / f"r_{mode}.npy")
     mp.spawn(_worker, args=(2, _free_port(), mode, out), nprocs=2, join=True)
-    got, full, got5, part5 = np.load(out)
+    got, full, got5, part5, other5 = np.load(out)
     assert full.mean() > 1e-3
     assert np.allclose(np.nan_to_num(got), np.nan_to_num(full), rtol=1e-12, atol=1e-14)
     assert np.allclose(np.nan_to_num(got5), np.nan_to_num(part5), rtol=1e-12, atol=1e-14)
+    assert np.allclose(np.nan_to_num(other5), np.nan_to_num(part5), rtol=1e-12, atol=1e-14)
+
+
+def test_a_gather_cannot_serve_the_strata_partition():
+    with pytest.raises(ValueError):
+        parallel.render_frame_job(lambda w, a: None, None, 8, 8, 4, dist=None, mode="strata", collective="gather")

@@ -5,7 +5,9 @@ with a smaller batch, so that stale scratch contents of the first call would sho
 
 Scenes: the Cornell box (transform chains: the scratch holds non-zero contexts), the Book-2 final scene
 (constant media, a hoisted first member: the split traversal), and a triangle mesh (the primitive-BVH
-kernel, which needs no scratch), in both traversal orders."""
+kernel, which needs no scratch), in both traversal orders.  The mesh batch is large enough (>= 2^18 rays on a tree
+whose rays cross many leaf boxes) for the allocating entry point to run its binning pass, which the allocation-free
+one must do without.  Free device memory is read before and after the allocation-free calls: they may not change it."""
 import numpy as np
 import pytest
 
@@ -56,8 +58,8 @@ def test_noalloc_entry_point_matches_allocating_one():
     world, lights, _ = scenes.book2_final(seed=0)
     cases.append((rt.SceneDesc.from_world(world, lights), [-200, 600, 0, 560, -200, 600]))
     cases.append((rt.SceneDesc.from_world(rt.Mesh(scenes.triangle_soup(20000, seed=13, edge=0.05), m)), [0, 1, 0, 1, 0, 1]))
-    n_first, n_second = 100000, 33333
-    for desc, box in cases:
+    for case, (desc, box) in enumerate(cases):
+        n_first, n_second = (300000, 33333) if case == 2 else (100000, 33333)
         gpu = rt.Scene(desc)
         o, d, tm = scenes.incoherent_rays(n_first, box, seed=41)
         rays = _device_rays(torch, dev, o, d, tm)
@@ -65,8 +67,13 @@ def test_noalloc_entry_point_matches_allocating_one():
             want_big = _query(torch, dev, gpu, rays, n_first, flags, noalloc=False)
             want_small = _query(torch, dev, gpu, rays, n_second, flags, noalloc=False)
             assert (want_big["prim"] != F.RT_REF_NONE).sum() > n_first // 10
+            hits = {f: torch.empty((n_first,), dtype=getattr(torch, _TORCH_DT.get(f, "float64")), device=dev) for f in HIT_FIELDS}
+            del hits  # (the caching allocator now holds the output buffers the calls below ask for)
+            torch.cuda.synchronize()
+            free_before = torch.cuda.mem_get_info(dev)[0]
             got_big = _query(torch, dev, gpu, rays, n_first, flags, noalloc=True)      # first call
             got_small = _query(torch, dev, gpu, rays, n_second, flags, noalloc=True)   # second call, smaller input
+            assert torch.cuda.mem_get_info(dev)[0] == free_before, "the allocation-free entry point changed the free device memory"
             _same(got_big, want_big)
             _same(got_small, want_small)
         gpu.close()
