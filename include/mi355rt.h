@@ -225,6 +225,13 @@ int rt_scene_get_wide_nodes(const rt_scene* scene, uint64_t first, uint64_t coun
  * RT_REF_TRI | index of the triangle in the description; box8 as above; box32 is zero.  `leaf_overlap`: sum of the
  * triangles' box areas over the world box's (how many triangle boxes a random line crosses).  Count 0: no packed tree. */
 int rt_scene_packed_node_count(const rt_scene* scene, uint64_t* count, double* leaf_overlap);
+/* The tree the nearest-first kernel walks when the world is one BVH over primitives: index of its root in the wide-node
+ * array, the number of triangle references in its packed form (0 without one), and whether it is a traversal-only tree
+ * (a mesh of MI355RT_FAST_TREE_MIN = 1024 triangles or more: surface-area heuristic with spatial splits instead of
+ * the collapse of the reference's median-split tree, bvh.rs:20-77, which RT_HIT_REFERENCE_ORDER and RT_HIT_EXACT_CULL
+ * keep walking; a triangle may then be the child of several nodes, each with the box of a part of it).  Any of the
+ * three out pointers may be NULL.  RT_E_INVALID when the world is not such a BVH. */
+int rt_scene_fast_tree_info(const rt_scene* scene, uint64_t* wide_root, uint64_t* references, int32_t* traversal_only);
 int rt_scene_get_packed_nodes(const rt_scene* scene, uint64_t first, uint64_t count, rt_wide_node* out);
 /* bounding_box() of an object of the description (hittable.rs:50), as 6 doubles. */
 int rt_scene_object_bounds(const rt_scene* scene, int32_t object, double out[6]);

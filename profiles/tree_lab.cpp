@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <functional>
 #include <limits>
 #include <string>
@@ -120,12 +121,16 @@ static int build(std::vector<Ref>& refs, int depth) {
             }
         }
         bool spatial = false; int s_axis = -1; double s_pos = 0; double s_cost = INF;
-        if (g_mode == 2 && best_axis >= 0 && g_refs_made < g_ref_budget) {
+        static const size_t spatial_max = getenv("SPATIAL_MAX_REFS") ? (size_t)atoll(getenv("SPATIAL_MAX_REFS")) : (size_t)-1;
+        static const int one_axis = getenv("SPATIAL_ONE_AXIS") ? atoi(getenv("SPATIAL_ONE_AXIS")) : 0;
+        static const size_t spatial_min = getenv("SPATIAL_MIN_REFS") ? (size_t)atoll(getenv("SPATIAL_MIN_REFS")) : 0;
+        if (g_mode == 2 && best_axis >= 0 && g_refs_made < g_ref_budget && refs.size() <= spatial_max && refs.size() >= spatial_min) {
             const double ov = isect(best_lb, best_rb).area();
             if (ov / g_root_area > g_alpha) {
                 for (int axis = 0; axis < 3; ++axis) {
                     const double ext = nb.hi[axis] - nb.lo[axis];
                     if (!(ext > 0)) continue;
+                    if (one_axis && axis != best_axis) continue;
                     Box bb[BINS]; uint32_t en[BINS] = {}, ex[BINS] = {};
                     for (auto& b : bb) b.reset();
                     const double sc = BINS / ext, w = ext / BINS;
@@ -292,7 +297,7 @@ int main(int argc, char** argv) {
         fprintf(stderr, "presplit at %g: %zu references (x%.2f)\n", thr, refs.size(), (double)refs.size() / N);
     }
     g_nodes.reserve(8 * N);
-    build(refs, 0);
+    { const clock_t c0 = clock(); build(refs, 0); fprintf(stderr, "build: %.1f s (one thread)\n", (double)(clock() - c0) / CLOCKS_PER_SEC); }
     size_t leaves = 0; double leaf_area = 0;
     for (auto& n : g_nodes) if (n.left < 0) { ++leaves; leaf_area += n.b.area(); }
     collapse(0);

@@ -149,6 +149,7 @@ PROTOTYPES = {
     "rt_scene_wide_node_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "rt_scene_get_wide_nodes": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(rt_wide_node)]),
     "rt_scene_packed_node_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
+    "rt_scene_fast_tree_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]),
     "rt_scene_get_packed_nodes": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(rt_wide_node)]),
     "rt_scene_object_bounds": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_double)]),
     "rt_obj_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.c_int32, C.POINTER(C.POINTER(rt_triangle)), C.POINTER(C.c_uint64)]),

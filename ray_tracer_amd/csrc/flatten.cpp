@@ -14,6 +14,7 @@
 //   - the precomputed quad / triangle constants (quad.rs:28-49, triangle.rs:122-125).
 // Nodes of one BVH are laid out in pre-order (left child = index + 1).
 #include "flatten.h"
+#include "fast_tree.h"
 
 #include <algorithm>
 #include <cmath>
@@ -164,6 +165,7 @@ struct Flattener {
     const rt_scene_desc* d;
     FlatScene& f;
     uint64_t device_bvh_min = 0;
+    uint64_t fast_tree_min = 0; // > 0: a primitive BVH over at least this many triangles gets a traversal-only tree (fast_tree.cpp)
     // BvhNode::new over `items` into nodes[base ...]: on the device when the BVH is large enough and holds no medium
     int build_nodes(std::vector<Item>& items, uint64_t base) {
         bool medium = false;
@@ -671,6 +673,35 @@ struct Flattener {
         return RT_OK;
     }
 
+    // When the BVH at binary node `root` holds nothing but triangles (a Mesh), the nearest-first kernel gets a tree of
+    // its own over them (fast_tree.cpp); the collapse of the reference tree stays where it is for the traversals that
+    // follow the reference's boxes.
+    int traversal_only_tree(uint32_t root) {
+        if (!fast_tree_min) return RT_OK;
+        std::vector<uint32_t> ids, todo{root};
+        while (!todo.empty()) {
+            const uint32_t i = todo.back(); todo.pop_back();
+            const DNode& n = f.nodes[i];
+            const uint32_t kids[2] = {n.left, n.right};
+            for (int k = 0; k < (n.left == n.right ? 1 : 2); ++k) {
+                if (RT_REF_KIND(kids[k]) == RT_REF_NODE) todo.push_back(RT_REF_INDEX(kids[k]));
+                else if (RT_REF_KIND(kids[k]) == RT_REF_TRI) ids.push_back(RT_REF_INDEX(kids[k]));
+                else return RT_OK; // spheres or quads among the leaves: the collapse of the reference tree serves
+            }
+        }
+        if (ids.size() < fast_tree_min) return RT_OK;
+        std::sort(ids.begin(), ids.end()); // description order: the tree does not depend on the reference tree's leaf order
+        uint32_t qroot = 0;
+        int32_t need = 0;
+        std::string e;
+        const int rc = build_fast_tree(f.tris.data(), ids.data(), ids.size(), f.qnodes, qdepth, qroot, need, e);
+        if (rc) return fail(rc, e);
+        f.fast_root = make_ref(REF_QNODE, qroot);
+        f.fast_stack = (uint32_t)need + 1;
+        f.fast_tree = true;
+        return RT_OK;
+    }
+
     // A list of 2..16 quads stored one after the other (box_new: quad.rs:140-190 pushes the six sides in a row)
     // is entered through a reference that names the quads directly.
     uint32_t quad_run(uint32_t ref) {
@@ -797,7 +828,12 @@ struct Flattener {
             }
             for (int k = n_inner; k < n_all; ++k) {
                 const uint32_t t = RT_REF_INDEX(c.child[order[k]]);
-                leaf_area += half_area(tri_box(t));
+                {   // the box this leaf is entered through (of the whole triangle, or of its part on this side of a spatial split)
+                    const QNode& w = f.qnodes[q];
+                    Box lb;
+                    for (int a = 0; a < 3; ++a) { lb.b[2 * a] = w.lo[a][order[k]]; lb.b[2 * a + 1] = w.hi[a][order[k]]; }
+                    leaf_area += half_area(lb);
+                }
                 PTri pt{};
                 for (int a = 0; a < 3; ++a) { pt.v0[a] = f.tris[t].v0[a]; pt.v1[a] = f.tris[t].v1[a]; pt.v2[a] = f.tris[t].v2[a]; }
                 pt.orig = t;
@@ -921,11 +957,15 @@ struct Flattener {
             need_q[root] = fill_qnode(me, root, 0);
             f.wnodes[root].qroot = me + 1;
         }
-        for (const QNode& q : f.qnodes)
-            for (int j = 0; j < 4; ++j)
-                if (q.child[j] != RT_REF_NONE)
-                    for (int a = 0; a < 3; ++a) f.q_extent = std::max(f.q_extent, std::max(std::fabs(q.lo[a][j]), std::fabs(q.hi[a][j])));
-        f.q_extent *= 1.0000001f;
+        auto measure_extent = [&]() {
+            f.q_extent = 0.0f;
+            for (const QNode& q : f.qnodes)
+                for (int j = 0; j < 4; ++j)
+                    if (q.child[j] != RT_REF_NONE)
+                        for (int a = 0; a < 3; ++a) f.q_extent = std::max(f.q_extent, std::max(std::fabs(q.lo[a][j]), std::fabs(q.hi[a][j])));
+            f.q_extent *= 1.0000001f;
+        };
+        measure_extent();
         {
             uint32_t r = f.world;
             if (RT_REF_KIND(r) == RT_REF_LIST && f.lists[RT_REF_INDEX(r)].count == 1) r = f.list_items[f.lists[RT_REF_INDEX(r)].first];
@@ -934,6 +974,8 @@ struct Flattener {
                 // the world is one BVH over primitives: the dedicated kernel traverses its 4-wide copy
                 f.fast_root = make_ref(REF_QNODE, f.wnodes[RT_REF_INDEX(r)].qroot - 1);
                 f.fast_stack = (uint32_t)need_q[RT_REF_INDEX(r)] + 1;
+                if (int rcf = traversal_only_tree(RT_REF_INDEX(r))) return rcf;
+                measure_extent();
                 f.quant_inflation = quantise_qnodes();
                 if (f.quant_inflation > 1.25) f.cqnodes.clear();
             }
@@ -942,6 +984,8 @@ struct Flattener {
             f.fast_root = make_ref(REF_QNODE, f.wnodes[(size_t)hoisted_root].qroot - 1);
             f.fast_stack = (uint32_t)need_q[(uint32_t)hoisted_root] + 1;
             if (hoist_whole_world) { // as if the world were that one BVH
+                if (int rcf = traversal_only_tree((uint32_t)hoisted_root)) return rcf;
+                measure_extent();
                 f.quant_inflation = quantise_qnodes();
                 if (f.quant_inflation > 1.25) f.cqnodes.clear();
             } else {
@@ -969,9 +1013,10 @@ struct Flattener {
 
 } // namespace
 
-int flatten_scene(const rt_scene_desc* desc, FlatScene& out, std::string& err, uint64_t device_bvh_min) {
+int flatten_scene(const rt_scene_desc* desc, FlatScene& out, std::string& err, uint64_t device_bvh_min, uint64_t fast_tree_min) {
     Flattener fl(desc, out, err);
     fl.device_bvh_min = device_bvh_min;
+    fl.fast_tree_min = fast_tree_min;
     return fl.run();
 }
 

@@ -43,6 +43,7 @@ struct FlatScene {
     uint32_t max_stack = 0;
     uint32_t fast_root = RT_REF_NONE; // set when the world is one BVH whose leaves are all primitives
     uint32_t fast_stack = 0;          // stack entries the primitive-BVH kernel needs
+    bool fast_tree = false;           // fast_root is a traversal-only tree (fast_tree.cpp): leaves may name a triangle more than once, with partial boxes
     bool fast_partial = false;        // fast_root covers only the FIRST member of the world list (rebuilt as one BVH over its
                                       // primitives); `world_rest` is the list of the remaining members, traversed afterwards
                                       // with the first member's closest hit as the interval's upper end (list order: hittable_list.rs:46-57)
@@ -64,7 +65,9 @@ int build_bvh_device(const BuildItem* items, uint64_t n, uint64_t base, DNode* n
 
 // Returns RT_OK or a negative RT_E_* code with `err` set.  device_bvh_min > 0: BVHs over at least that many objects
 // (none of them holding a constant medium) are built on the current HIP device.
-int flatten_scene(const rt_scene_desc* desc, FlatScene& out, std::string& err, uint64_t device_bvh_min = 0);
+// fast_tree_min > 0: a world that is one BVH over at least that many triangles (a Mesh) also gets a traversal-only tree
+// for the nearest-first kernel (fast_tree.cpp); fast_root then names that tree.
+int flatten_scene(const rt_scene_desc* desc, FlatScene& out, std::string& err, uint64_t device_bvh_min = 0, uint64_t fast_tree_min = 0);
 
 // Camera::initialize (camera.rs:161-205).
 int camera_initialize(const rt_camera* cam, rt_camera_derived* out, std::string& err);

@@ -198,6 +198,7 @@ Tuning read_tuning() {
     t.debug = getenv("MI355RT_DEBUG") != nullptr;
     t.fast_blocks_per_cu = env_int("MI355RT_FAST_BLOCKS_PER_CU", 0);
     t.device_bvh_min = (uint64_t)std::max(0, env_int("MI355RT_DEVICE_BVH_MIN", (int)t.device_bvh_min));
+    t.fast_tree_min = (uint64_t)std::max(0, env_int("MI355RT_FAST_TREE_MIN", (int)t.fast_tree_min));
     t.reorder_min = (uint64_t)std::max(1, env_int("MI355RT_REORDER_MIN", (int)t.reorder_min));
     t.tail_paths = (uint64_t)std::max(0, env_int("MI355RT_TAIL_PATHS", TAIL_PATHS));
     // Paths per render batch.  17 GB of path records and queues when a frame is that large (the workspace is sized
@@ -654,7 +655,7 @@ int rt_scene_create(const rt_scene_desc* desc, uint32_t flags, rt_scene** out) {
         if (e != hipSuccess) { delete s; return set_err(RT_E_HIP, std::string("no HIP device: ") + hipGetErrorString(e)); }
     }
     // large BVHs are built on the device (bvh_build.hip), in the same split order as the host recursion
-    int rc = flatten_scene(desc, s->flat, err, (flags & RT_SCENE_HOST_ONLY) ? 0 : s->tune.device_bvh_min);
+    int rc = flatten_scene(desc, s->flat, err, (flags & RT_SCENE_HOST_ONLY) ? 0 : s->tune.device_bvh_min, s->tune.fast_tree_min);
     if (rc) { delete s; return set_err(rc, err); }
     if (flags & RT_SCENE_HOST_ONLY) {
         s->host_only = true;
@@ -757,6 +758,15 @@ int rt_scene_packed_node_count(const rt_scene* s, uint64_t* count, double* leaf_
     *count = s->flat.pnodes.size();
     if (leaf_overlap) *leaf_overlap = s->flat.fast_leaf_overlap;
     return RT_OK;
+}
+
+int rt_scene_fast_tree_info(const rt_scene* s, uint64_t* wide_root, uint64_t* references, int32_t* traversal_only) {
+    if (!s) return set_err(RT_E_INVALID, "rt_scene_fast_tree_info: null scene");
+    const bool have = s->flat.fast_root != RT_REF_NONE;
+    if (wide_root) *wide_root = have ? RT_REF_INDEX(s->flat.fast_root) : 0;
+    if (references) *references = s->flat.ptris.size();
+    if (traversal_only) *traversal_only = s->flat.fast_tree ? 1 : 0;
+    return have ? RT_OK : set_err(RT_E_INVALID, "rt_scene_fast_tree_info: the world is not one BVH over primitives");
 }
 
 int rt_scene_get_packed_nodes(const rt_scene* s, uint64_t first, uint64_t count, rt_wide_node* out) {

@@ -154,6 +154,7 @@ struct Tuning {
     int reorder = 1;             // MI355RT_REORDER: binning pass in front of large closest-hit batches: 0 never, 1 where it pays (below), 2 always
     bool debug = false;          // MI355RT_DEBUG: diagnostics on stderr
     uint64_t device_bvh_min = 1ull << 15; // MI355RT_DEVICE_BVH_MIN: BVHs over at least this many objects are built on the device (0 = never)
+    uint64_t fast_tree_min = 1024; // MI355RT_FAST_TREE_MIN: meshes of at least this many triangles get a traversal-only tree (0 = never)
     int fast_blocks_per_cu = 0;  // MI355RT_FAST_BLOCKS_PER_CU: cap on the primitive-BVH kernel's workgroups per CU (occupancy experiments)
     uint64_t reorder_min = 1ull << 18; // smallest batch that is binned
     uint64_t tail_paths = 1ull << 16;

@@ -292,6 +292,12 @@ class Scene:
         dt = np.dtype([("child", "<u4", 4), ("box32", "<f8", (4, 6)), ("box8", "<f8", (4, 6)), ("has_box8", "<i4"), ("_pad", "<i4")])
         return np.frombuffer(buf, dtype=dt, count=n).copy(), overlap.value
 
+    def fast_tree_info(self):
+        """(index of the nearest-first kernel's root in wide_nodes(), triangle references of its packed form, traversal-only?)"""
+        root, refs, only = C.c_uint64(0), C.c_uint64(0), C.c_int32(0)
+        F.check(F.lib.rt_scene_fast_tree_info(self._h, C.byref(root), C.byref(refs), C.byref(only)))
+        return int(root.value), int(refs.value), bool(only.value)
+
     def object_bounds(self, obj: int) -> np.ndarray:
         out = (C.c_double * 6)()
         F.check(F.lib.rt_scene_object_bounds(self._h, obj, out))

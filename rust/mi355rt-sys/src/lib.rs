@@ -61,6 +61,7 @@ extern "C" {
     pub fn rt_scene_wide_node_count(scene: *const rt_scene, count: *mut u64) -> c_int;
     pub fn rt_scene_get_wide_nodes(scene: *const rt_scene, first: u64, count: u64, out: *mut rt_wide_node) -> c_int;
     pub fn rt_scene_packed_node_count(scene: *const rt_scene, count: *mut u64, leaf_overlap: *mut f64) -> c_int;
+    pub fn rt_scene_fast_tree_info(scene: *const rt_scene, wide_root: *mut u64, references: *mut u64, traversal_only: *mut i32) -> c_int;
     pub fn rt_scene_get_packed_nodes(scene: *const rt_scene, first: u64, count: u64, out: *mut rt_wide_node) -> c_int;
     pub fn rt_scene_object_bounds(scene: *const rt_scene, object: i32, out: *mut f64) -> c_int;
     pub fn rt_obj_load(path: *const c_char, scale_offset: *const f64, mat: i32, triangles: *mut *mut rt_triangle, n_triangles: *mut u64) -> c_int;

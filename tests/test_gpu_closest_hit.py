@@ -559,26 +559,38 @@ def test_rays_at_shared_edges_and_vertices_from_far_away(monkeypatch):
     """Rays aimed exactly at the vertices and edge midpoints of a closed mesh, from origins up to 10^5 scene sizes away:
     the triangles around a vertex are hit within a few f32 units in the last place of each other (or at the same t), and
     their boxes are entered at nearly the same distance.  The entry distance a deferred subtree is stored with must
-    stay a lower bound, or the pop-time cull drops the subtree that holds the closer triangle.  Closest t must be the
-    oracle's bit for bit, with batches traced as they come and through the binning pass."""
+    stay a lower bound, or the pop-time cull drops the subtree that holds the closer triangle.
+    The yardstick is the closest hit over ALL triangles, i.e. the oracle's linear scan of the same triangles (ObjModel,
+    obj_loader.rs:86-101): such rays touch triangle boxes at single points, which Aabb::hit culls (aabb.rs:102) and the
+    conservative boxes of the ordered traversal do not, so the reference's BVH itself misses some of these hits (the
+    documented deviation of RT_HIT_ORDERED); the ordered traversal must not miss any, with batches traced as they come
+    and through the binning pass."""
     m = rt.Lambertian(rt.Color(.5, .5, .5))
     tris = scenes.icosphere_mesh(subdiv=4)
     desc = rt.SceneDesc.from_world(rt.Mesh(tris, m))
+    scan = O.OracleScene(rt.SceneDesc.from_world(rt.ObjModel(tris, m)))
     g = np.random.default_rng(77)
     verts = tris.reshape(-1, 3)
     mids = 0.5 * (tris[:, 0] + tris[:, 1])
-    targets = np.concatenate([verts[g.integers(0, len(verts), 6000)], mids[g.integers(0, len(mids), 6000)]])
+    targets = np.concatenate([verts[g.integers(0, len(verts), 3000)], mids[g.integers(0, len(mids), 3000)]])
     dirs = g.normal(size=targets.shape)
     dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
     for pass_on in (False, True):
         if pass_on:
             monkeypatch.setenv("MI355RT_REORDER_MIN", "1")
             monkeypatch.setenv("MI355RT_REORDER", "2")
+        gpu = rt.Scene(desc)
         for dist, unit in ((3.0, False), (1e3, True), (1e5, True), (1e5, False)):
             o = targets - dirs * dist
             d = dirs if unit else (targets - o)  # unit directions: t ~ dist; unnormalised: t ~ 1
-            # (several triangles meet at every target: exact ties are the rule here, and any of the tied triangles may be reported)
-            compare(desc, o, d, min_hits=6000, flags=F.RT_HIT_ORDERED, max_ties=0.9)
+            a = gpu.closest_hit(o, d, flags=F.RT_HIT_ORDERED)
+            b = scan.closest_hit(o, d, nthreads=8)
+            assert (b["prim"] != F.RT_REF_NONE).sum() >= 5500
+            assert np.array_equal(a["t"].view(np.uint64), b["t"].view(np.uint64)), (dist, unit, pass_on)
+            same = a["prim"] == b["prim"]  # several triangles meet at every target: any of those tied at the closest t may be reported
+            for f in ("u", "v", "front_face", "mat", "nx", "ny", "nz"):
+                assert np.array_equal(a[f][same], b[f][same]), f
+        gpu.close()
 
 
 def test_one_scene_from_several_threads():

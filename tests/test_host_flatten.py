@@ -163,23 +163,22 @@ def test_resolve_equals_oracle_and_ppm(tmp_path):
     assert lines[3] == " ".join(str(int(v)) for v in img.rgb[0, 0])
 
 
-def test_packed_tree_is_the_wide_tree_relaid():
-    """The 48-byte nodes of a triangle mesh (children addressed from two base indices, inner children first, triangles
-    in leaf order) describe the same tree as the 64-byte nodes they are made from: walked side by side from the roots,
-    every node has the same children with the same 8-bit boxes, and every triangle of the mesh is a leaf exactly once."""
-    m = rt.Lambertian(rt.Color(.5, .5, .5))
-    n_tris = 3001
-    s = rt.Scene(rt.Mesh(scenes.triangle_soup(n_tris, seed=17, edge=0.06), m), host_only=True)
+def _walk_packed_beside_wide(s, n_tris):
+    """Walks the 48-byte nodes and the 64-byte nodes they are made from side by side, from the roots: every node must
+    have the same children with the same 8-bit boxes.  Returns how often every triangle is a leaf, and the sum of the
+    leaf boxes' half areas (f32 boxes)."""
     wide = s.wide_nodes()
     packed, overlap = s.packed_nodes()
-    assert len(packed) > n_tris // 4 and wide[0]["has_box8"] == 1
-    assert len(packed) < len(wide)  # dense: the 64-byte array is indexed like the binary tree
+    root, refs, only = s.fast_tree_info()
+    assert len(packed) > n_tris // 4 and wide[root]["has_box8"] == 1
+    assert len(packed) < len(wide)  # dense: the 64-byte array keeps padding nodes (and the reference tree's collapse)
     seen = np.zeros(n_tris, dtype=int)
-    todo = [(0, 0)]
+    leaf_area = 0.0
+    todo = [(root, 0)]
     kind = lambda r: int(r) >> 28
     while todo:
         w, p = todo.pop()
-        wc = {tuple(wide[w]["box8"][j]): int(wide[w]["child"][j]) for j in range(4) if wide[w]["child"][j] != F.RT_REF_NONE}
+        wc = {tuple(wide[w]["box8"][j]): (int(wide[w]["child"][j]), j) for j in range(4) if wide[w]["child"][j] != F.RT_REF_NONE}
         pc = [(tuple(packed[p]["box8"][j]), int(packed[p]["child"][j])) for j in range(4) if packed[p]["child"][j] != F.RT_REF_NONE]
         assert len(wc) == len(pc), (w, p)
         kinds = [kind(r) for _, r in pc]
@@ -187,22 +186,87 @@ def test_packed_tree_is_the_wide_tree_relaid():
         for box, ref in pc:
             assert box in wc, (w, p, box)
             if kind(ref) == F.RT_REF_NODE:
-                assert kind(wc[box]) == F.RT_REF_NODE
-                todo.append((wc[box] & 0x0FFFFFFF, ref & 0x0FFFFFFF))
+                assert kind(wc[box][0]) == F.RT_REF_NODE
+                todo.append((wc[box][0] & 0x0FFFFFFF, ref & 0x0FFFFFFF))
             else:
-                assert ref == wc[box] and kind(ref) == F.RT_REF_TRI
+                assert ref == wc[box][0] and kind(ref) == F.RT_REF_TRI
                 seen[ref & 0x0FFFFFFF] += 1
-    assert (seen == 1).all()
-    # boxes a random line through the world box crosses: sum of triangle box areas / world box area
+                b32 = wide[w]["box32"][wc[box][1]]
+                e = b32[1::2] - b32[0::2]
+                leaf_area += e[0] * e[1] + e[1] * e[2] + e[2] * e[0]
+    assert seen.sum() == refs
+    return seen, leaf_area, overlap, only
+
+
+def test_packed_tree_is_the_wide_tree_relaid(monkeypatch):
+    """The 48-byte nodes of a triangle mesh (children addressed from two base indices, inner children first, triangles
+    in leaf order) describe the same tree as the 64-byte nodes they are made from.  With the collapse of the reference's
+    tree every triangle of the mesh is a leaf exactly once; the traversal-only tree (meshes of 1024 triangles or more)
+    may name a triangle from several leaves."""
+    m = rt.Lambertian(rt.Color(.5, .5, .5))
+    n_tris = 3001
     tri = scenes.triangle_soup(n_tris, seed=17, edge=0.06)
-    ext = tri.max(axis=1) - tri.min(axis=1)
     area = lambda e: e[..., 0] * e[..., 1] + e[..., 1] * e[..., 2] + e[..., 2] * e[..., 0]
+    monkeypatch.setenv("MI355RT_FAST_TREE_MIN", "0")
+    s = rt.Scene(rt.Mesh(tri, m), host_only=True)
+    seen, leaf_area, overlap, only = _walk_packed_beside_wide(s, n_tris)
+    assert not only and (seen == 1).all()
+    # boxes a random line through the world box crosses: sum of triangle box areas / world box area
+    ext = tri.max(axis=1) - tri.min(axis=1)
     wb = np.array(s.info().world_bounds[:]).reshape(3, 2)
     assert abs(overlap - area(ext).sum() / area(wb[:, 1] - wb[:, 0])) < 0.05 * overlap
+    monkeypatch.delenv("MI355RT_FAST_TREE_MIN")
+    s2 = rt.Scene(rt.Mesh(tri, m), host_only=True)
+    seen2, leaf_area2, overlap2, only2 = _walk_packed_beside_wide(s2, n_tris)
+    assert only2 and (seen2 >= 1).all() and seen2.sum() <= 2 * n_tris
+    assert abs(overlap2 - leaf_area2 / area(wb[:, 1] - wb[:, 0])) < 0.01 * overlap2 and overlap2 < overlap
     lst = rt.HittableList()
     lst.add(rt.Sphere(rt.Point3(0, 0, 0), 1.0, m))
     lst.add(rt.Triangle(rt.Point3(0, 0, 2), rt.Point3(1, 0, 2), rt.Point3(0, 1, 2), m))
     assert len(rt.Scene(rt.BvhNode(lst), host_only=True).packed_nodes()[0]) == 0  # not all triangles: no packed tree
+
+
+def test_traversal_only_tree_covers_every_point_of_every_triangle():
+    """The traversal-only tree splits space as well as objects: a triangle that straddles a split plane is a leaf on
+    both sides, each time with the box of its part.  Whatever point of a triangle a ray hits, the ray must be able to
+    reach the triangle through boxes that contain the point: from the root there has to be a chain of child boxes
+    (8-bit boxes of the packed nodes, and the f32 boxes of the wide nodes) that all contain the point and ends in a
+    leaf naming that triangle.  Checked for corners, edge midpoints, centroids and random interior points of every
+    triangle of a soup (overlapping triangles) and of a closed surface (shared edges)."""
+    m = rt.Lambertian(rt.Color(.5, .5, .5))
+    g = np.random.default_rng(3)
+    for tri in (scenes.triangle_soup(2500, seed=23, edge=0.08), scenes.icosphere_mesh(subdiv=3)):
+        n_tris = len(tri)
+        s = rt.Scene(rt.Mesh(tri, m), host_only=True)
+        root, refs, only = s.fast_tree_info()
+        assert only and refs >= n_tris
+        packed, _ = s.packed_nodes()
+        wide = s.wide_nodes()
+        w = g.dirichlet([1.0, 1.0, 1.0], size=(n_tris, 4))
+        bary = np.concatenate([np.tile(np.array([[1., 0, 0], [0, 1., 0], [0, 0, 1.], [.5, .5, 0], [0, .5, .5], [.5, 0, .5], [1 / 3, 1 / 3, 1 / 3]]), (n_tris, 1, 1)), w], axis=1)
+        pts = np.einsum("nkv,nvc->nkc", bary, tri)  # (n_tris, 11, 3)
+        for nodes, start in ((packed, 0), (wide, root)):
+            boxes = "box8" if nodes is packed else "box32"
+            child = nodes["child"]
+            bx = nodes[boxes]
+            for t in range(n_tris):
+                for p in pts[t]:
+                    todo, found = [start], False
+                    while todo and not found:
+                        i = todo.pop()
+                        for j in range(4):
+                            r = int(child[i][j])
+                            if r == F.RT_REF_NONE:
+                                continue
+                            b = bx[i][j]
+                            if not (b[0] <= p[0] <= b[1] and b[2] <= p[1] <= b[3] and b[4] <= p[2] <= b[5]):
+                                continue
+                            if (r >> 28) == F.RT_REF_NODE:
+                                todo.append(r & 0x0FFFFFFF)
+                            elif r == ((F.RT_REF_TRI << 28) | t):
+                                found = True
+                                break
+                    assert found, (t, p)
 
 
 def test_errors_are_reported_not_panicked():
