@@ -10,27 +10,38 @@
 // reference is tested with the exact f64 intersector on the WHOLE triangle (triangle.rs:153-199), so a ray finds the
 // triangle's hit through whichever reference box it enters first, at the same t, bit for bit.
 //
-// On the 2^20-triangle soup (triangles as large as their spacing) this tree costs a ray 22 % fewer node steps and 12 %
-// fewer triangle tests than the 4-wide collapse of the reference tree, at 1.4 references per triangle; on a closed
-// surface, where boxes hardly overlap, the gain is the heuristic's alone (8 % fewer node steps).
+// On the 2^20-triangle soup (triangles as large as their spacing) a ray makes 27.4 node steps and 5.7 triangle tests in
+// this tree against 36.8 and 6.5 in the 4-wide collapse of the reference tree, at 1.35 references per triangle; on a
+// closed surface, where boxes hardly overlap, the gain is the heuristic's alone (12.9 against 14.0 node steps).
+//
+// Three passes, each a recursion whose large subtrees run as tasks of their own: (1) the binary tree, partitioning the
+// references in place (a spatial split copies its node's references once); (2) which binary nodes become 4-wide nodes
+// and how many of those every subtree holds; (3) with those counts every 4-wide node knows where it and its children
+// go, and writes its record in all the formats the kernels read (QNode, CQNode, PNode + PTri: device_types.h).
 #include "fast_tree.h"
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <future>
 #include <limits>
+#include <memory>
 #include <thread>
-#include <chrono>
-#include <cstdio>
-#include <cstdlib>
+
+#include "quantise.h"
 
 namespace rt {
 namespace {
 
 constexpr int BINS = 16;
-constexpr size_t SPATIAL_MIN = 64;
+constexpr size_t SPATIAL_MIN = 256;   // spatial splits are searched in nodes of at least this many references
+constexpr size_t SWEEP_MAX = 8;       // nodes of at most this many references are split by an exact sweep along one axis
+constexpr size_t TASK_MIN = 8192;     // subtrees of at least this many references may run as tasks of their own
+constexpr size_t CHUNK_MIN = 1 << 17; // nodes of at least this many references bin their references in parallel chunks
 constexpr float FINF = std::numeric_limits<float>::infinity();
 
 struct FBox {
@@ -54,18 +65,48 @@ struct FRef { FBox b; uint32_t tri; };
 inline float down32(double x) { float f = (float)x; if ((double)f > x) f = std::nextafterf(f, -FINF); return f; }
 inline float up32(double x) { float f = (float)x; if ((double)f < x) f = std::nextafterf(f, FINF); return f; }
 
-struct BNode { FBox b; int32_t left, right; uint32_t tri; }; // leaf: left < 0
+struct BNode {
+    FBox b;
+    int32_t left, right;  // leaf: left < 0
+    uint32_t tri;         // leaf: index into the builder's triangle list
+    uint32_t leaves;      // references below this node
+    uint32_t wide;        // pass 2: 4-wide nodes below this node when it is the root of one, itself included
+};
+
+struct ObjBins {
+    FBox box[3][BINS];
+    uint32_t cnt[3][BINS];
+    void reset() { for (int a = 0; a < 3; ++a) for (int i = 0; i < BINS; ++i) { box[a][i].reset(); cnt[a][i] = 0; } }
+    void merge(const ObjBins& o) { for (int a = 0; a < 3; ++a) for (int i = 0; i < BINS; ++i) { box[a][i].grow(o.box[a][i]); cnt[a][i] += o.cnt[a][i]; } }
+};
+struct SpaBins {
+    FBox box[BINS];
+    uint32_t en[BINS], ex[BINS];
+    void reset() { for (int i = 0; i < BINS; ++i) { box[i].reset(); en[i] = ex[i] = 0; } }
+    void merge(const SpaBins& o) { for (int i = 0; i < BINS; ++i) { box[i].grow(o.box[i]); en[i] += o.en[i]; ex[i] += o.ex[i]; } }
+};
 
 struct Builder {
-    const DTri* tris;
-    const uint32_t* ids;        // triangle numbers in DScene::tris
-    std::vector<BNode> pool;
+    const DTri* tris = nullptr;
+    const uint32_t* ids = nullptr; // triangle numbers in DScene::tris
+    std::unique_ptr<BNode[]> pool;
+    size_t pool_size = 0;
     std::atomic<uint32_t> next{0};
-    std::atomic<int64_t> spare; // references that spatial splits may still add
+    std::atomic<int64_t> spare{0}; // references that spatial splits may still add
     std::atomic<int> tasks{0};
     int max_tasks = 1;
     float root_area = 1.0f;
-    bool overflow = false;
+    std::atomic<bool> overflow{false};
+
+    // Runs fn(begin, end, part) over `parts` near-equal pieces of [0, n), the first on this thread.
+    template <class Fn>
+    void chunks(size_t n, int parts, Fn fn) {
+        std::vector<std::future<void>> jobs;
+        for (int p = 1; p < parts; ++p) jobs.push_back(std::async(std::launch::async, [=]() { fn(n * (size_t)p / (size_t)parts, n * (size_t)(p + 1) / (size_t)parts, p); }));
+        fn(0, n / (size_t)parts, 0);
+        for (auto& j : jobs) j.get();
+    }
+    int parts_for(size_t n) const { return n >= CHUNK_MIN ? std::max(1, std::min(max_tasks + 1, 8)) : 1; }
 
     // Box of the part of triangle t with lo <= x[axis] <= hi, rounded outward to f32 (the clipping arithmetic's own
     // rounding is covered by a relative pad far below the f32 step).
@@ -101,88 +142,167 @@ struct Builder {
         return r;
     }
 
+    // The same box in plain f32 arithmetic, for the search among candidate planes (where a box that is off by a rounding
+    // only changes an estimate); the split that is finally made uses clip().
+    FBox clip_estimate(uint32_t t, int axis, float lo, float hi) const {
+        const DTri& T = tris[ids[t]];
+        const float v[3][3] = {{(float)T.v0[0], (float)T.v0[1], (float)T.v0[2]}, {(float)T.v1[0], (float)T.v1[1], (float)T.v1[2]}, {(float)T.v2[0], (float)T.v2[1], (float)T.v2[2]}};
+        FBox r; r.reset();
+        for (int i = 0; i < 3; ++i) {
+            const float* a = v[i];
+            const float* b = v[(i + 1) % 3];
+            if (a[axis] >= lo && a[axis] <= hi)
+                for (int k = 0; k < 3; ++k) { r.lo[k] = std::min(r.lo[k], a[k]); r.hi[k] = std::max(r.hi[k], a[k]); }
+            const float da = a[axis], db = b[axis];
+            if (da == db) continue;
+            const float inv = 1.0f / (db - da);
+            for (int side = 0; side < 2; ++side) {
+                const float plane = side == 0 ? lo : hi;
+                if ((da < plane && db > plane) || (da > plane && db < plane)) {
+                    const float s = (plane - da) * inv;
+                    for (int k = 0; k < 3; ++k) { const float p = k == axis ? plane : a[k] + s * (b[k] - a[k]); r.lo[k] = std::min(r.lo[k], p); r.hi[k] = std::max(r.hi[k], p); }
+                }
+            }
+        }
+        return r;
+    }
+
     uint32_t alloc() {
         const uint32_t i = next.fetch_add(1);
-        if (i >= pool.size()) { overflow = true; return (uint32_t)pool.size() - 1; }
+        if (i >= pool_size) { overflow = true; return (uint32_t)pool_size - 1; }
         return i;
     }
 
-    uint32_t build(std::vector<FRef>& refs, int depth) {
+    // Two subtrees, the first as a task of its own when it is large and a thread is free.
+    template <class FnL, class FnR>
+    void both(size_t n_left, FnL left, FnR right) {
+        if (n_left >= TASK_MIN && tasks.load(std::memory_order_relaxed) < max_tasks) {
+            ++tasks;
+            auto fut = std::async(std::launch::async, [&]() { left(); --tasks; });
+            right();
+            fut.get();
+        } else {
+            left();
+            right();
+        }
+    }
+
+    // ---------------------------------------------------------------------------------------------- pass 1: binary tree
+    // refs[0, n) belong to this call and are permuted in place.
+    uint32_t build(FRef* refs, size_t n, int depth) {
         const uint32_t me = alloc();
-        FBox nb; nb.reset();
-        for (const FRef& r : refs) nb.grow(r.b);
-        pool[me].b = nb;
-        pool[me].left = pool[me].right = -1;
-        pool[me].tri = refs[0].tri;
-        const size_t n = refs.size();
-        if (n == 1 || overflow) return me;
-        std::vector<FRef> L, R;
-        bool done = false;
-        if (n > 2 && depth < 60) {
-            // object split: surface-area heuristic over BINS centroid bins, all three axes in one pass
-            FBox cb; cb.reset();
-            for (const FRef& r : refs)
-                for (int k = 0; k < 3; ++k) { const float c = 0.5f * (r.b.lo[k] + r.b.hi[k]); cb.lo[k] = std::min(cb.lo[k], c); cb.hi[k] = std::max(cb.hi[k], c); }
-            FBox bins[3][BINS];
-            uint32_t cnt[3][BINS];
-            float sc[3];
-            for (int a = 0; a < 3; ++a) {
-                const float ext = cb.hi[a] - cb.lo[a];
-                sc[a] = ext > 0.0f ? (float)BINS / ext : 0.0f;
-                for (int i = 0; i < BINS; ++i) { bins[a][i].reset(); cnt[a][i] = 0; }
-            }
-            for (const FRef& r : refs)
-                for (int a = 0; a < 3; ++a) {
-                    int b = (int)((0.5f * (r.b.lo[a] + r.b.hi[a]) - cb.lo[a]) * sc[a]);
-                    b = b < 0 ? 0 : (b >= BINS ? BINS - 1 : b);
-                    bins[a][b].grow(r.b);
-                    ++cnt[a][b];
+        BNode& node = pool[me];
+        node.left = node.right = -1;
+        node.tri = refs[0].tri;
+        node.leaves = 1;
+        node.wide = 0;
+        if (n == 1 || overflow) { node.b = refs[0].b; return me; }
+        const int parts = parts_for(n);
+        FBox nb, cb; // box of the references, box of their centres
+        nb.reset(); cb.reset();
+        {
+            std::vector<FBox> pn(parts), pc(parts);
+            chunks(n, parts, [&](size_t lo, size_t hi, int p) {
+                FBox a, c; a.reset(); c.reset();
+                for (size_t i = lo; i < hi; ++i) {
+                    a.grow(refs[i].b);
+                    for (int k = 0; k < 3; ++k) { const float m = 0.5f * (refs[i].b.lo[k] + refs[i].b.hi[k]); c.lo[k] = std::min(c.lo[k], m); c.hi[k] = std::max(c.hi[k], m); }
                 }
+                pn[p] = a; pc[p] = c;
+            });
+            for (int p = 0; p < parts; ++p) { nb.grow(pn[p]); cb.grow(pc[p]); }
+        }
+        node.b = nb;
+        size_t n_left = 0;             // in-place result: refs[0, n_left) | refs[n_left, n)
+        std::vector<FRef> copy;        // a spatial split's references: left part, then right part
+        size_t copy_left = 0;
+        bool done = false;
+        if (n > 2 && n <= SWEEP_MAX && depth < 60) {
+            // few references: order them by centre along the longest axis of the centres' box and try every cut
+            int a = 0;
+            for (int k = 1; k < 3; ++k) if (cb.hi[k] - cb.lo[k] > cb.hi[a] - cb.lo[a]) a = k;
+            if (cb.hi[a] - cb.lo[a] > 0.0f) {
+                std::sort(refs, refs + n, [a](const FRef& x, const FRef& y) { return x.b.lo[a] + x.b.hi[a] < y.b.lo[a] + y.b.hi[a]; });
+                FBox suffix[SWEEP_MAX];
+                FBox acc; acc.reset();
+                for (size_t i = n; i-- > 1;) { acc.grow(refs[i].b); suffix[i] = acc; }
+                acc.reset();
+                float best = FINF;
+                for (size_t i = 1; i < n; ++i) {
+                    acc.grow(refs[i - 1].b);
+                    const float cost = acc.area() * (float)i + suffix[i].area() * (float)(n - i);
+                    if (cost < best) { best = cost; n_left = i; }
+                }
+                done = n_left > 0;
+            }
+        } else if (n > SWEEP_MAX && depth < 60) {
+            // object split: surface-area heuristic over BINS bins of the centres, all three axes in one pass
+            float sc[3];
+            for (int a = 0; a < 3; ++a) { const float ext = cb.hi[a] - cb.lo[a]; sc[a] = ext > 0.0f ? (float)BINS / ext : 0.0f; }
+            auto bin_of = [&](const FRef& r, int a) {
+                int b = (int)((0.5f * (r.b.lo[a] + r.b.hi[a]) - cb.lo[a]) * sc[a]);
+                return b < 0 ? 0 : (b >= BINS ? BINS - 1 : b);
+            };
+            std::vector<ObjBins> ob(parts);
+            chunks(n, parts, [&](size_t lo, size_t hi, int p) {
+                ObjBins& o = ob[p];
+                o.reset();
+                for (size_t i = lo; i < hi; ++i)
+                    for (int a = 0; a < 3; ++a) { const int b = bin_of(refs[i], a); o.box[a][b].grow(refs[i].b); ++o.cnt[a][b]; }
+            });
+            for (int p = 1; p < parts; ++p) ob[0].merge(ob[p]);
+            const ObjBins& bins = ob[0];
             float best = FINF; int best_axis = -1, best_bin = 0; FBox best_l, best_r;
             for (int a = 0; a < 3; ++a) {
                 if (!(sc[a] > 0.0f)) continue;
                 FBox rb[BINS]; uint32_t rc[BINS];
                 FBox acc; acc.reset(); uint32_t c = 0;
-                for (int i = BINS - 1; i > 0; --i) { acc.grow(bins[a][i]); c += cnt[a][i]; rb[i] = acc; rc[i] = c; }
+                for (int i = BINS - 1; i > 0; --i) { acc.grow(bins.box[a][i]); c += bins.cnt[a][i]; rb[i] = acc; rc[i] = c; }
                 acc.reset(); c = 0;
                 for (int i = 1; i < BINS; ++i) {
-                    acc.grow(bins[a][i - 1]); c += cnt[a][i - 1];
+                    acc.grow(bins.box[a][i - 1]); c += bins.cnt[a][i - 1];
                     if (c == 0 || rc[i] == 0) continue;
                     const float cost = acc.area() * (float)c + rb[i].area() * (float)rc[i];
                     if (cost < best) { best = cost; best_axis = a; best_bin = i; best_l = acc; best_r = rb[i]; }
                 }
             }
-            // spatial split along the same axis, where the halves of the object split overlap
-            bool spatial = false; float s_pos = 0.0f;
-            // (only in nodes of SPATIAL_MIN references or more: measured on the 2^20-triangle soup, the splits that pay are
-            // those near the top of the tree -- with them in every node a ray makes 27.55 node steps, from 64 references
-            // on 27.60, from 1024 on 28.2, without any 31.6 -- and near the leaves a reference spans many bins, so the
-            // search there is where most of its clipping time goes)
+            // Spatial split along the same axis, where the halves of the object split overlap.  Only in nodes of
+            // SPATIAL_MIN references or more: measured on the 2^20-triangle soup, the splits that pay are those near the
+            // top of the tree (with them in every node a ray makes 27.55 node steps, from 64 references on 27.60, from
+            // 1024 on 28.2, without any 31.6), and near the leaves a reference spans many bins, which is where the
+            // search's clipping time goes.
             if (n >= SPATIAL_MIN && best_axis >= 0 && spare.load(std::memory_order_relaxed) > 0 && meet(best_l, best_r).area() > 1e-6f * root_area) {
                 const int a = best_axis;
                 const float ext = nb.hi[a] - nb.lo[a];
+                bool spatial = false; float s_pos = 0.0f;
                 if (ext > 0.0f) {
-                    FBox sb[BINS]; uint32_t en[BINS], ex[BINS];
-                    for (int i = 0; i < BINS; ++i) { sb[i].reset(); en[i] = ex[i] = 0; }
                     const float ssc = (float)BINS / ext, w = ext / (float)BINS;
-                    for (const FRef& r : refs) {
-                        int b0 = (int)((r.b.lo[a] - nb.lo[a]) * ssc), b1 = (int)((r.b.hi[a] - nb.lo[a]) * ssc);
-                        b0 = b0 < 0 ? 0 : (b0 >= BINS ? BINS - 1 : b0);
-                        b1 = b1 < b0 ? b0 : (b1 >= BINS ? BINS - 1 : b1);
-                        ++en[b0]; ++ex[b1];
-                        if (b0 == b1) { sb[b0].grow(r.b); continue; }
-                        for (int b = b0; b <= b1; ++b) {
-                            const FBox c = meet(clip(r.tri, a, (double)(nb.lo[a] + (float)b * w), (double)(nb.lo[a] + (float)(b + 1) * w)), r.b);
-                            if (c.valid()) sb[b].grow(c);
+                    std::vector<SpaBins> sb(parts);
+                    chunks(n, parts, [&](size_t lo, size_t hi, int p) {
+                        SpaBins& s = sb[p];
+                        s.reset();
+                        for (size_t i = lo; i < hi; ++i) {
+                            const FRef& r = refs[i];
+                            int b0 = (int)((r.b.lo[a] - nb.lo[a]) * ssc), b1 = (int)((r.b.hi[a] - nb.lo[a]) * ssc);
+                            b0 = b0 < 0 ? 0 : (b0 >= BINS ? BINS - 1 : b0);
+                            b1 = b1 < b0 ? b0 : (b1 >= BINS ? BINS - 1 : b1);
+                            ++s.en[b0]; ++s.ex[b1];
+                            if (b0 == b1) { s.box[b0].grow(r.b); continue; }
+                            for (int b = b0; b <= b1; ++b) {
+                                const FBox c = meet(clip_estimate(r.tri, a, nb.lo[a] + (float)b * w, nb.lo[a] + (float)(b + 1) * w), r.b);
+                                if (c.valid()) s.box[b].grow(c);
+                            }
                         }
-                    }
+                    });
+                    for (int p = 1; p < parts; ++p) sb[0].merge(sb[p]);
+                    const SpaBins& s = sb[0];
                     FBox rb[BINS]; uint32_t rc[BINS];
                     FBox acc; acc.reset(); uint32_t c = 0;
-                    for (int i = BINS - 1; i > 0; --i) { acc.grow(sb[i]); c += ex[i]; rb[i] = acc; rc[i] = c; }
+                    for (int i = BINS - 1; i > 0; --i) { acc.grow(s.box[i]); c += s.ex[i]; rb[i] = acc; rc[i] = c; }
                     acc.reset(); c = 0;
                     float s_cost = FINF;
                     for (int i = 1; i < BINS; ++i) {
-                        acc.grow(sb[i - 1]); c += en[i - 1];
+                        acc.grow(s.box[i - 1]); c += s.en[i - 1];
                         if (c == 0 || rc[i] == 0) continue;
                         const float cost = acc.area() * (float)c + rb[i].area() * (float)rc[i];
                         if (cost < s_cost) { s_cost = cost; s_pos = nb.lo[a] + (float)i * w; }
@@ -190,135 +310,102 @@ struct Builder {
                     spatial = s_cost < best;
                 }
                 if (spatial) {
-                    L.reserve(n); R.reserve(n);
+                    std::vector<FRef> right;
+                    copy.reserve(n + n / 4); right.reserve(n / 2 + n / 8);
                     int64_t added = 0;
-                    for (const FRef& r : refs) {
-                        if (r.b.hi[a] <= s_pos) L.push_back(r);
-                        else if (r.b.lo[a] >= s_pos) R.push_back(r);
+                    for (size_t i = 0; i < n; ++i) {
+                        const FRef& r = refs[i];
+                        if (r.b.hi[a] <= s_pos) copy.push_back(r);
+                        else if (r.b.lo[a] >= s_pos) right.push_back(r);
                         else {
                             FRef l = r, rr = r;
                             l.b = meet(clip(r.tri, a, -1e300, (double)s_pos), r.b);
                             rr.b = meet(clip(r.tri, a, (double)s_pos, 1e300), r.b);
                             const bool lv = l.b.valid(), rv = rr.b.valid();
-                            if (lv) L.push_back(l);
-                            if (rv) R.push_back(rr);
+                            if (lv) copy.push_back(l);
+                            if (rv) right.push_back(rr);
                             if (lv && rv) ++added;
-                            if (!lv && !rv) L.push_back(r); // (cannot happen for a box that straddles the plane; never lose a reference)
+                            if (!lv && !rv) copy.push_back(r); // (cannot happen for a box that straddles the plane; never lose a reference)
                         }
                     }
-                    if (L.empty() || R.empty() || L.size() == n || R.size() == n) { L.clear(); R.clear(); spatial = false; }
-                    else { spare.fetch_sub(added, std::memory_order_relaxed); done = true; }
+                    if (copy.empty() || right.empty() || copy.size() == n || right.size() == n) { copy.clear(); }
+                    else {
+                        copy_left = copy.size();
+                        copy.insert(copy.end(), right.begin(), right.end());
+                        spare.fetch_sub(added, std::memory_order_relaxed);
+                        done = true;
+                    }
                 }
             }
             if (!done && best_axis >= 0) {
-                L.reserve(n); R.reserve(n);
-                for (const FRef& r : refs) {
-                    int b = (int)((0.5f * (r.b.lo[best_axis] + r.b.hi[best_axis]) - cb.lo[best_axis]) * sc[best_axis]);
-                    b = b < 0 ? 0 : (b >= BINS ? BINS - 1 : b);
-                    (b < best_bin ? L : R).push_back(r);
-                }
-                done = !L.empty() && !R.empty();
-                if (!done) { L.clear(); R.clear(); }
+                const int a = best_axis;
+                n_left = (size_t)(std::partition(refs, refs + n, [&](const FRef& r) { return bin_of(r, a) < best_bin; }) - refs);
+                done = n_left > 0 && n_left < n;
             }
         }
-        if (!done) { // two references, all centroids equal, or too deep: halve
-            L.assign(refs.begin(), refs.begin() + n / 2);
-            R.assign(refs.begin() + n / 2, refs.end());
-        }
-        std::vector<FRef>().swap(refs);
-        uint32_t l, r;
-        if (n > 16384 && tasks.load() < max_tasks) {
-            ++tasks;
-            auto fut = std::async(std::launch::async, [&]() { const uint32_t x = build(L, depth + 1); --tasks; return x; });
-            r = build(R, depth + 1);
-            l = fut.get();
-        } else {
-            l = build(L, depth + 1);
-            r = build(R, depth + 1);
-        }
-        pool[me].left = (int32_t)l;
-        pool[me].right = (int32_t)r;
+        if (!done) n_left = n / 2; // two references, all centres equal, or too deep: halve
+        FRef* lp = copy.empty() ? refs : copy.data();
+        const size_t ln = copy.empty() ? n_left : copy_left, rn = copy.empty() ? n - n_left : copy.size() - copy_left;
+        FRef* rp = lp + ln;
+        uint32_t l = 0, r = 0;
+        both(ln, [&]() { l = build(lp, ln, depth + 1); }, [&]() { r = build(rp, rn, depth + 1); });
+        BNode& again = pool[me];
+        again.left = (int32_t)l;
+        again.right = (int32_t)r;
+        again.leaves = pool[l].leaves + pool[r].leaves;
         return me;
     }
-};
 
-} // namespace
-
-int build_fast_tree(const DTri* tris, const uint32_t* tri_ids, uint64_t n, std::vector<QNode>& qnodes, std::vector<uint8_t>& qdepth,
-                    uint32_t& root_out, int32_t& stack_need, std::string& err) {
-    if (n < 2 || n >= (1ull << 27)) { err = "fast tree: triangle count out of range"; return RT_E_TOO_LARGE; }
-    Builder B;
-    B.tris = tris;
-    B.ids = tri_ids;
-    const uint64_t extra = n;                       // spatial splits may add up to one more reference per triangle
-    B.pool.resize(2 * (n + extra) + 64);
-    B.spare = (int64_t)extra;
-    B.max_tasks = (int)std::min<unsigned>(15u, std::max(1u, std::thread::hardware_concurrency()) - 1u);
-    std::vector<FRef> refs(n);
-    FBox root; root.reset();
-    for (uint64_t i = 0; i < n; ++i) {
-        const DTri& T = tris[tri_ids[i]];
-        FRef& r = refs[i];
-        r.tri = (uint32_t)i;
-        for (int k = 0; k < 3; ++k) {
-            double lo = std::fmin(std::fmin(T.v0[k], T.v1[k]), T.v2[k]), hi = std::fmax(std::fmax(T.v0[k], T.v1[k]), T.v2[k]);
-            if (hi - lo < 0.0001) { lo -= 0.00005; hi += 0.00005; } // as the reference pads thin boxes (aabb.rs:125-136)
-            r.b.lo[k] = down32(lo); r.b.hi[k] = up32(hi);
-        }
-        if (!r.b.valid() || !std::isfinite(r.b.area())) { err = "fast tree: non-finite triangle"; return RT_E_INVALID; }
-        root.grow(r.b);
-    }
-    B.root_area = std::max(root.area(), 1e-30f);
-    const bool debug = getenv("MI355RT_DEBUG") != nullptr;
-    const auto t_0 = std::chrono::steady_clock::now();
-    const uint32_t broot = B.build(refs, 0);
-    const auto t_1 = std::chrono::steady_clock::now();
-    if (B.overflow) { err = "fast tree: node pool exhausted"; return RT_E_TOO_LARGE; }
-
-    // Collapse into 4-wide nodes: starting from a node's two children, the inner child with the largest box is
-    // replaced by its own two children until four are there.  Inner children of a node get consecutive indices
-    // starting at an even one (siblings share 128-byte lines in the 64-byte format).
-    struct Job { uint32_t bnode, qnode; int depth; };
-    auto add_empty = [&]() {
-        QNode q{};
-        for (int j = 0; j < 4; ++j) {
-            q.child[j] = RT_REF_NONE;
-            for (int a = 0; a < 3; ++a) { q.lo[a][j] = FINF; q.hi[a][j] = -FINF; }
-        }
-        qnodes.push_back(q);
-        qdepth.push_back(255);
-    };
-    if (qnodes.size() & 1u) add_empty();
-    root_out = (uint32_t)qnodes.size();
-    add_empty();
-    std::vector<Job> todo{Job{broot, root_out, 0}};
-    std::vector<std::pair<uint32_t, uint32_t>> parent_of; // (qnode, parent qnode) in creation order, for the stack need
-    parent_of.emplace_back(root_out, RT_REF_NONE);
-    while (!todo.empty()) {
-        const Job job = todo.back(); todo.pop_back();
-        uint32_t kids[4]; int nk = 0;
-        kids[nk++] = (uint32_t)B.pool[job.bnode].left;
-        kids[nk++] = (uint32_t)B.pool[job.bnode].right;
+    // ------------------------------------------------------------------- pass 2: which nodes become 4-wide, and how many
+    // The children of the 4-wide node rooted at binary node v: starting from v's two children, the inner child with the
+    // largest box is replaced by its own two children until four are there.  Inner children first.
+    int wide_children(uint32_t v, uint32_t kids[4]) const {
+        int nk = 0;
+        kids[nk++] = (uint32_t)pool[v].left;
+        kids[nk++] = (uint32_t)pool[v].right;
         while (nk < 4) {
             int best = -1; float ba = -1.0f;
             for (int i = 0; i < nk; ++i)
-                if (B.pool[kids[i]].left >= 0 && B.pool[kids[i]].b.area() > ba) { ba = B.pool[kids[i]].b.area(); best = i; }
+                if (pool[kids[i]].left >= 0 && pool[kids[i]].b.area() > ba) { ba = pool[kids[i]].b.area(); best = i; }
             if (best < 0) break;
             const uint32_t k = kids[best];
-            kids[best] = (uint32_t)B.pool[k].left;
-            kids[nk++] = (uint32_t)B.pool[k].right;
+            kids[best] = (uint32_t)pool[k].left;
+            kids[nk++] = (uint32_t)pool[k].right;
         }
-        int n_inner = 0;
-        for (int i = 0; i < nk; ++i) n_inner += B.pool[kids[i]].left >= 0 ? 1 : 0;
-        uint32_t base = 0;
-        if (n_inner) {
-            if (qnodes.size() & 1u) add_empty();
-            base = (uint32_t)qnodes.size();
-            for (int i = 0; i < n_inner; ++i) add_empty();
+        std::stable_partition(kids, kids + nk, [&](uint32_t k) { return pool[k].left >= 0; });
+        return nk;
+    }
+    // Returns the stack entries a nearest-first traversal below v can need; sets pool[v].wide.
+    int32_t count(uint32_t v) {
+        uint32_t kids[4];
+        const int nk = wide_children(v, kids);
+        uint32_t wide = 1;
+        int32_t deepest = 0;
+        int32_t need[4] = {0, 0, 0, 0};
+        int inner = 0;
+        for (int j = 0; j < nk; ++j) inner += pool[kids[j]].left >= 0 ? 1 : 0;
+        if (inner >= 2 && pool[v].leaves >= TASK_MIN) {
+            both(pool[kids[0]].leaves, [&]() { need[0] = count(kids[0]); }, [&]() { for (int j = 1; j < inner; ++j) need[j] = count(kids[j]); });
+        } else {
+            for (int j = 0; j < inner; ++j) need[j] = count(kids[j]);
         }
-        if (qnodes.size() >= (1ull << 28)) { err = "fast tree: more than 2^28 wide nodes"; return RT_E_TOO_LARGE; }
+        for (int j = 0; j < inner; ++j) { wide += pool[kids[j]].wide; deepest = std::max(deepest, need[j]); }
+        pool[v].wide = wide;
+        return (nk - 1) + deepest; // up to nk - 1 siblings stay deferred while one child is walked
+    }
+
+    // -------------------------------------------------------------------------------------------- pass 3: the records
+    QNode* qn = nullptr; CQNode* cq = nullptr; PNode* pn = nullptr; PTri* pt = nullptr; uint8_t* qd = nullptr;
+    uint32_t q_first = 0;     // index of the tree's root in the scene's qnodes / cqnodes
+    bool packed = false;
+    // 4-wide node rooted at binary node v: record `at` (0 = root), its inner children at records [kids_at, ...), its
+    // triangles at ptris [leaves_at, ...); everything below the children follows behind them, subtree by subtree.
+    void emit(uint32_t v, uint32_t at, uint32_t kids_at, uint32_t leaves_at, int depth) {
+        uint32_t kids[4];
+        const int nk = wide_children(v, kids);
+        int inner = 0;
+        for (int j = 0; j < nk; ++j) inner += pool[kids[j]].left >= 0 ? 1 : 0;
         QNode q{};
-        int k = 0;
         for (int j = 0; j < 4; ++j) {
             q._pad[j] = 0;
             if (j >= nk) {
@@ -326,35 +413,131 @@ int build_fast_tree(const DTri* tris, const uint32_t* tri_ids, uint64_t n, std::
                 for (int a = 0; a < 3; ++a) { q.lo[a][j] = FINF; q.hi[a][j] = -FINF; }
                 continue;
             }
-            const BNode& c = B.pool[kids[j]];
+            const BNode& c = pool[kids[j]];
             for (int a = 0; a < 3; ++a) { q.lo[a][j] = c.b.lo[a]; q.hi[a][j] = c.b.hi[a]; }
-            if (c.left >= 0) {
-                const uint32_t child = base + (uint32_t)k++;
-                q.child[j] = make_ref(REF_QNODE, child);
-                todo.push_back(Job{kids[j], child, job.depth + 1});
-                parent_of.emplace_back(child, job.qnode);
-            } else {
-                q.child[j] = make_ref(RT_REF_TRI, tri_ids[c.tri]);
+            q.child[j] = j < inner ? make_ref(REF_QNODE, q_first + kids_at + (uint32_t)j) : make_ref(RT_REF_TRI, ids[c.tri]);
+        }
+        qn[at] = q;
+        qd[at] = (uint8_t)std::min(depth, 255);
+        CQNode c8{};
+        quantise_node(q, c8);
+        cq[at] = c8;
+        if (packed) {
+            PNode p{};
+            for (int a = 0; a < 3; ++a) { p.origin[a] = c8.origin[a]; p.exp[a] = c8.exp[a]; }
+            p.counts = (uint8_t)(inner | (nk << 4));
+            for (int k = 0; k < 4; ++k)
+                for (int a = 0; a < 3; ++a) { p.qlo[a][k] = c8.qlo[a][k]; p.qhi[a][k] = c8.qhi[a][k]; }
+            p.node_base = make_ref(REF_QNODE, kids_at);
+            p.leaf_base = make_ref(RT_REF_TRI, leaves_at) - (uint32_t)inner;
+            pn[at] = p;
+            for (int j = inner; j < nk; ++j) {
+                const DTri& T = tris[ids[pool[kids[j]].tri]];
+                PTri t{};
+                for (int a = 0; a < 3; ++a) { t.v0[a] = T.v0[a]; t.v1[a] = T.v1[a]; t.v2[a] = T.v2[a]; }
+                t.orig = ids[pool[kids[j]].tri];
+                pt[leaves_at + (uint32_t)(j - inner)] = t;
             }
         }
-        qnodes[job.qnode] = q;
-        qdepth[job.qnode] = (uint8_t)std::min(job.depth, 255);
+        // the children's own children and triangles follow, subtree by subtree
+        uint32_t below_at[4], below_leaves[4];
+        uint32_t next_at = kids_at + (uint32_t)inner, next_leaves = leaves_at + (uint32_t)(nk - inner);
+        for (int j = 0; j < inner; ++j) {
+            below_at[j] = next_at; below_leaves[j] = next_leaves;
+            next_at += pool[kids[j]].wide - 1u;
+            next_leaves += pool[kids[j]].leaves;
+        }
+        if (inner >= 2 && pool[v].leaves >= TASK_MIN) {
+            both(pool[kids[0]].leaves, [&]() { emit(kids[0], kids_at, below_at[0], below_leaves[0], depth + 1); },
+                 [&]() { for (int j = 1; j < inner; ++j) emit(kids[j], kids_at + (uint32_t)j, below_at[j], below_leaves[j], depth + 1); });
+        } else {
+            for (int j = 0; j < inner; ++j) emit(kids[j], kids_at + (uint32_t)j, below_at[j], below_leaves[j], depth + 1);
+        }
     }
-    // stack entries a traversal below the root can need: up to (children - 1) siblings stay deferred per level
-    std::vector<int32_t> need(qnodes.size() - root_out, 0);
-    for (size_t i = parent_of.size(); i-- > 0;) { // children were created after their parents: walk backwards
-        const uint32_t qn = parent_of[i].first, par = parent_of[i].second;
-        int cnt = 0;
-        for (int j = 0; j < 4; ++j) cnt += qnodes[qn].child[j] != RT_REF_NONE ? 1 : 0;
-        const int32_t mine = std::max(0, cnt - 1) + need[qn - root_out]; // need[] holds the deepest child's need so far
-        need[qn - root_out] = mine;
-        if (par != RT_REF_NONE) need[par - root_out] = std::max(need[par - root_out], mine);
+};
+
+} // namespace
+
+int build_fast_tree(const DTri* tris, FlatScene& f, std::vector<uint8_t>& qdepth, const uint32_t* tri_ids, uint64_t n, FastTreeResult& out, std::string& err) {
+    if (n < 2 || n >= (1ull << 27)) { err = "fast tree: triangle count out of range"; return RT_E_TOO_LARGE; }
+    const bool debug = getenv("MI355RT_DEBUG") != nullptr;
+    const auto t_0 = std::chrono::steady_clock::now();
+    Builder B;
+    B.tris = tris;
+    B.ids = tri_ids;
+    const uint64_t extra = n;                       // spatial splits may add up to one more reference per triangle
+    B.pool_size = 2 * (n + extra) + 64;
+    B.pool.reset(new BNode[B.pool_size]);
+    B.spare = (int64_t)extra;
+    B.max_tasks = (int)std::min<unsigned>(15u, std::max(1u, std::thread::hardware_concurrency()) - 1u);
+    std::unique_ptr<FRef[]> refs(new FRef[n]);
+    {
+        const int parts = B.parts_for(n);
+        std::vector<FBox> roots(parts);
+        std::atomic<bool> bad{false};
+        B.chunks(n, parts, [&](size_t lo, size_t hi, int p) {
+            FBox root; root.reset();
+            for (size_t i = lo; i < hi; ++i) {
+                const DTri& T = B.tris[tri_ids[i]];
+                FRef& r = refs[i];
+                r.tri = (uint32_t)i;
+                for (int k = 0; k < 3; ++k) {
+                    double l = std::fmin(std::fmin(T.v0[k], T.v1[k]), T.v2[k]), h = std::fmax(std::fmax(T.v0[k], T.v1[k]), T.v2[k]);
+                    if (h - l < 0.0001) { l -= 0.00005; h += 0.00005; } // as the reference pads thin boxes (aabb.rs:125-136)
+                    r.b.lo[k] = down32(l); r.b.hi[k] = up32(h);
+                }
+                if (!r.b.valid() || !std::isfinite(r.b.area())) bad = true;
+                root.grow(r.b);
+            }
+            roots[p] = root;
+        });
+        if (bad) { err = "fast tree: non-finite triangle"; return RT_E_INVALID; }
+        FBox root; root.reset();
+        for (const FBox& b : roots) root.grow(b);
+        B.root_area = std::max(root.area(), 1e-30f);
     }
-    stack_need = need[0];
-    if (debug)
-        std::fprintf(stderr, "[mi355rt] traversal-only tree: %llu triangles, %u binary nodes, %zu wide nodes, build %.3f s, collapse %.3f s\n", (unsigned long long)n,
-                     B.next.load(), qnodes.size() - root_out, std::chrono::duration<double>(t_1 - t_0).count(),
-                     std::chrono::duration<double>(std::chrono::steady_clock::now() - t_1).count());
+    const auto t_1 = std::chrono::steady_clock::now();
+    const uint32_t broot = B.build(refs.get(), n, 0);
+    if (B.overflow) { err = "fast tree: node pool exhausted"; return RT_E_TOO_LARGE; }
+    refs.reset();
+    const auto t_2 = std::chrono::steady_clock::now();
+    out.stack_need = B.count(broot);
+    const uint64_t wide = B.pool[broot].wide, leaves = B.pool[broot].leaves;
+    const size_t first = f.qnodes.size();
+    if (first + wide >= (1ull << 28)) { err = "fast tree: more than 2^28 wide nodes"; return RT_E_TOO_LARGE; }
+    // (the kernel addresses the packed arrays by 32-bit byte offsets: they stay below 4 GB; larger meshes keep the 64-byte nodes)
+    B.packed = (wide + 4u) * sizeof(PNode) < (1ull << 32) && (leaves + 4u) * sizeof(PTri) < (1ull << 32);
+    f.qnodes.resize(first + wide);
+    f.cqnodes.resize(first + wide);
+    qdepth.resize(first + wide);
+    f.pnodes.clear(); f.ptris.clear();
+    if (B.packed) { f.pnodes.resize(wide); f.ptris.resize(leaves); }
+    B.qn = f.qnodes.data() + first; B.cq = f.cqnodes.data() + first; B.qd = qdepth.data() + first;
+    B.pn = f.pnodes.data(); B.pt = f.ptris.data();
+    B.q_first = (uint32_t)first;
+    B.emit(broot, 0u, 1u, 0u, 0);
+    out.root = (uint32_t)first;
+    out.wide_nodes = wide;
+    out.references = leaves;
+    // the measures the flattener keeps: area of the leaf boxes, and how much the 8-bit grid inflates the boxes near the root
+    out.leaf_area = 0.0; out.ratio_sum = 0.0; out.ratio_n = 0;
+    for (uint64_t i = 0; i < wide; ++i) {
+        const QNode& q = B.qn[i];
+        for (int j = 0; j < 4; ++j) {
+            if (q.child[j] == RT_REF_NONE) continue;
+            if (RT_REF_KIND(q.child[j]) == RT_REF_TRI) {
+                const double dx = (double)q.hi[0][j] - q.lo[0][j], dy = (double)q.hi[1][j] - q.lo[1][j], dz = (double)q.hi[2][j] - q.lo[2][j];
+                out.leaf_area += dx * dy + dy * dz + dz * dx;
+            }
+            if (B.qd[i] < 4) { const double r = quantised_area_ratio(q, B.cq[i], j); if (r >= 0.0) { out.ratio_sum += r; ++out.ratio_n; } }
+        }
+    }
+    if (debug) {
+        const auto t_3 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[mi355rt] traversal-only tree: %llu triangles, %llu references, %llu wide nodes; set-up %.3f s, binary tree %.3f s, records %.3f s (%d tasks)\n",
+                     (unsigned long long)n, (unsigned long long)leaves, (unsigned long long)wide, std::chrono::duration<double>(t_1 - t_0).count(),
+                     std::chrono::duration<double>(t_2 - t_1).count(), std::chrono::duration<double>(t_3 - t_2).count(), B.max_tasks);
+    }
     return RT_OK;
 }
 

@@ -15,9 +15,13 @@
 // Nodes of one BVH are laid out in pre-order (left child = index + 1).
 #include "flatten.h"
 #include "fast_tree.h"
+#include "quantise.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <future>
 #include <limits>
 #include <map>
@@ -678,29 +682,86 @@ struct Flattener {
     // follow the reference's boxes.
     int traversal_only_tree(uint32_t root) {
         if (!fast_tree_min) return RT_OK;
-        std::vector<uint32_t> ids, todo{root};
-        while (!todo.empty()) {
-            const uint32_t i = todo.back(); todo.pop_back();
-            const DNode& n = f.nodes[i];
-            const uint32_t kids[2] = {n.left, n.right};
-            for (int k = 0; k < (n.left == n.right ? 1 : 2); ++k) {
-                if (RT_REF_KIND(kids[k]) == RT_REF_NODE) todo.push_back(RT_REF_INDEX(kids[k]));
-                else if (RT_REF_KIND(kids[k]) == RT_REF_TRI) ids.push_back(RT_REF_INDEX(kids[k]));
-                else return RT_OK; // spheres or quads among the leaves: the collapse of the reference tree serves
-            }
+        FastTreeResult res;
+        if (early.started && (early.root != root || !f.qnodes.empty())) { // not the BVH it was started for after all: drop it
+            (void)early.done.get();
+            early.started = false;
+            early.scene = FlatScene();
         }
-        if (ids.size() < fast_tree_min) return RT_OK;
-        std::sort(ids.begin(), ids.end()); // description order: the tree does not depend on the reference tree's leaf order
-        uint32_t qroot = 0;
-        int32_t need = 0;
-        std::string e;
-        const int rc = build_fast_tree(f.tris.data(), ids.data(), ids.size(), f.qnodes, qdepth, qroot, need, e);
-        if (rc) return fail(rc, e);
-        f.fast_root = make_ref(REF_QNODE, qroot);
-        f.fast_stack = (uint32_t)need + 1;
+        if (early.started) {
+            // built beside the reference BVHs (start_early_fast_tree): its arrays become the first nodes of the scene's
+            const int rc = early.done.get();
+            early.started = false;
+            if (rc) return fail(rc, early.err);
+            f.qnodes = std::move(early.scene.qnodes);
+            f.cqnodes = std::move(early.scene.cqnodes);
+            f.pnodes = std::move(early.scene.pnodes);
+            f.ptris = std::move(early.scene.ptris);
+            qdepth = std::move(early.depth);
+            res = early.res;
+            fast_tree_first = 0;
+        } else {
+            std::vector<uint32_t> ids, todo{root};
+            while (!todo.empty()) {
+                const uint32_t i = todo.back(); todo.pop_back();
+                const DNode& n = f.nodes[i];
+                const uint32_t kids[2] = {n.left, n.right};
+                for (int k = 0; k < (n.left == n.right ? 1 : 2); ++k) {
+                    if (RT_REF_KIND(kids[k]) == RT_REF_NODE) todo.push_back(RT_REF_INDEX(kids[k]));
+                    else if (RT_REF_KIND(kids[k]) == RT_REF_TRI) ids.push_back(RT_REF_INDEX(kids[k]));
+                    else return RT_OK; // spheres or quads among the leaves: the collapse of the reference tree serves
+                }
+            }
+            if (ids.size() < fast_tree_min) return RT_OK;
+            std::sort(ids.begin(), ids.end()); // description order: the tree does not depend on the reference tree's leaf order
+            std::string e;
+            fast_tree_first = f.qnodes.size();
+            const int rc = build_fast_tree(f.tris.data(), f, qdepth, ids.data(), ids.size(), res, e);
+            if (rc) return fail(rc, e);
+        }
+        f.fast_root = make_ref(REF_QNODE, res.root);
+        f.fast_stack = (uint32_t)res.stack_need + 1;
         f.fast_tree = true;
+        fast_ratio_sum = res.ratio_sum; fast_ratio_n = res.ratio_n;
+        fast_leaf_area = res.leaf_area;
+        // the general kernel's nearest-first traversal enters the same tree at this BVH's root
+        need_q[root] = res.stack_need;
+        f.wnodes[root].qroot = res.root + 1;
         return RT_OK;
     }
+    // The common case, a world that is a Mesh (a BVH declared over a range of triangles): the traversal-only tree needs
+    // nothing but the triangles, so it is built on threads of its own while this one builds the reference's BVHs.
+    struct EarlyFastTree {
+        bool started = false;
+        uint32_t root = 0;       // first binary node of the BVH it belongs to
+        std::future<int> done;
+        FlatScene scene;         // holds the tree's arrays until they are merged
+        std::vector<uint8_t> depth;
+        std::vector<uint32_t> ids;
+        FastTreeResult res;
+        std::string err;
+    } early;
+    void start_early_fast_tree() {
+        if (!fast_tree_min || d->world < 0 || (uint64_t)d->world >= d->n_objects) return;
+        const rt_object* o = &d->objects[d->world];
+        if (o->kind == RT_OBJ_LIST && o->child_kind == RT_CHILD_OBJECTS && o->b == 1 && o->a >= 0 && (uint64_t)o->a < d->n_children) {
+            const int32_t c = d->children[o->a];
+            if (c < 0 || c >= d->world) return;
+            o = &d->objects[c];
+        }
+        if (o->kind != RT_OBJ_BVH || o->child_kind != RT_CHILD_TRIANGLES || o->a < 0 || o->b < 0) return;
+        if ((uint64_t)o->a + (uint64_t)o->b > d->n_triangles || (uint64_t)o->b < fast_tree_min) return;
+        early.ids.resize((size_t)o->b);
+        for (int32_t k = 0; k < o->b; ++k) early.ids[(size_t)k] = (uint32_t)(o->a + k);
+        early.root = 0; // the world's BVH is the first one built: its nodes start the node array
+        early.started = true;
+        early.done = std::async(std::launch::async, [this]() {
+            return build_fast_tree(f.tris.data(), early.scene, early.depth, early.ids.data(), early.ids.size(), early.res, early.err);
+        });
+    }
+    size_t fast_tree_first = 0;   // first of the traversal-only tree's nodes in qnodes (they come with their 8-bit and packed forms)
+    double fast_ratio_sum = 0.0, fast_leaf_area = 0.0;
+    uint64_t fast_ratio_n = 0;
 
     // A list of 2..16 quads stored one after the other (box_new: quad.rs:140-190 pushes the six sides in a row)
     // is entered through a reference that names the quads directly.
@@ -731,59 +792,34 @@ struct Flattener {
     // ratio capped at 16: close to 1 when siblings are of similar size, large when one huge primitive forces
     // a coarse grid onto its small neighbours all the way up the tree (then the f32 nodes are the better choice).
     double quantise_qnodes() {
-        f.cqnodes.resize(f.qnodes.size());
-        double ratio_sum = 0.0;
-        uint64_t ratio_n = 0;
-        auto area = [](const double* lo, const double* hi) {
-            const double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
-            return dx * dy + dy * dz + dz * dx;
-        };
-        for (size_t i = 0; i < f.qnodes.size(); ++i) {
-            const QNode& s = f.qnodes[i];
-            CQNode q{};
-            int n = 0;
-            for (int j = 0; j < 4; ++j) { q.child[j] = s.child[j]; if (s.child[j] != RT_REF_NONE) n = j + 1; }
-            double step[3];
-            for (int a = 0; a < 3; ++a) {
-                float lo = s.lo[a][0], hi = s.hi[a][0];
-                for (int j = 1; j < n; ++j) { lo = std::min(lo, s.lo[a][j]); hi = std::max(hi, s.hi[a][j]); }
-                q.origin[a] = lo;
-                const double extent = (double)hi - (double)lo;
-                int e = 1; // biased exponent of the grid step (a normal float): 255 steps must span the extent
-                if (extent > 0.0) {
-                    int ex;
-                    std::frexp(extent / 255.0, &ex);
-                    e = std::min(254, std::max(1, ex + 127));
-                    while (e < 254 && std::ldexp(255.0, e - 127) < extent) ++e;
-                }
-                q.exp[a] = (uint8_t)e;
-                step[a] = std::ldexp(1.0, e - 127);
+        f.cqnodes.resize(f.qnodes.size()); // (the traversal-only tree has brought its 8-bit nodes along: fast_tree.cpp)
+        double ratio_sum = fast_ratio_sum;
+        uint64_t ratio_n = fast_ratio_n;
+        const size_t limit = f.fast_tree ? fast_tree_first : f.qnodes.size();
+        for (size_t i = 0; i < limit; ++i) {
+            quantise_node(f.qnodes[i], f.cqnodes[i]);
+            if (qdepth[i] < 4)
                 for (int j = 0; j < 4; ++j) {
-                    if (j >= n) { q.qlo[a][j] = 255; q.qhi[a][j] = 0; continue; } // never tested: the slot's child is RT_REF_NONE
-                    const double l = (double)s.lo[a][j] - (double)lo, h = (double)s.hi[a][j] - (double)lo;
-                    double ql = std::floor(l / step[a]), qh = std::ceil(h / step[a]);
-                    while (ql > 0.0 && ql * step[a] > l) ql -= 1.0;
-                    while (qh < 255.0 && qh * step[a] < h) qh += 1.0;
-                    q.qlo[a][j] = (uint8_t)std::min(255.0, std::max(0.0, ql));
-                    q.qhi[a][j] = (uint8_t)std::min(255.0, std::max(0.0, qh));
+                    if (f.qnodes[i].child[j] == RT_REF_NONE) continue;
+                    const double r = quantised_area_ratio(f.qnodes[i], f.cqnodes[i], j);
+                    if (r >= 0.0) { ratio_sum += r; ++ratio_n; }
                 }
-            }
-            for (int j = 0; j < n; ++j) {
-                double lo32[3], hi32[3], loq[3], hiq[3];
-                for (int a = 0; a < 3; ++a) {
-                    lo32[a] = s.lo[a][j]; hi32[a] = s.hi[a][j];
-                    loq[a] = q.origin[a] + q.qlo[a][j] * step[a]; hiq[a] = q.origin[a] + q.qhi[a][j] * step[a];
-                }
-                const double a32 = area(lo32, hi32), aq = area(loq, hiq);
-                if (qdepth[i] < 4 && a32 > 0.0 && std::isfinite(aq)) { ratio_sum += std::min(aq / a32, 16.0); ++ratio_n; }
-            }
-            f.cqnodes[i] = q;
         }
         return ratio_n ? ratio_sum / (double)ratio_n : 1.0;
     }
 
     // Packed copy (PNode / PTri) of the 8-bit tree at fast_root, when every leaf below it is a triangle.
     void pack_fast_tree() {
+        auto half = [](const Box& b) {
+            const double dx = b.b[1] - b.b[0], dy = b.b[3] - b.b[2], dz = b.b[5] - b.b[4];
+            return dx * dy + dy * dz + dz * dx;
+        };
+        if (f.fast_tree) { // packed by fast_tree.cpp; the 8-bit boxes may have been rejected since
+            if (f.cqnodes.empty() || f.fast_partial) { f.pnodes.clear(); f.ptris.clear(); }
+            const double wa = half(f.world_bounds);
+            f.fast_leaf_overlap = wa > 0.0 ? fast_leaf_area / wa : 0.0;
+            return;
+        }
         f.pnodes.clear();
         f.ptris.clear();
         if (f.cqnodes.empty() || f.fast_root == RT_REF_NONE || f.fast_partial) return;
@@ -896,6 +932,15 @@ struct Flattener {
         }
     }
 
+    // MI355RT_DEBUG: where the time of a scene's set-up goes
+    std::chrono::steady_clock::time_point t_mark = std::chrono::steady_clock::now();
+    const bool debug = getenv("MI355RT_DEBUG") != nullptr;
+    void stage(const char* name) {
+        const auto now = std::chrono::steady_clock::now();
+        if (debug) std::fprintf(stderr, "[mi355rt] flatten: %-28s %.3f s\n", name, std::chrono::duration<double>(now - t_mark).count());
+        t_mark = now;
+    }
+
     int run() {
         int rc;
         if (!d) return fail(RT_E_INVALID, "null scene description");
@@ -906,11 +951,16 @@ struct Flattener {
         f.images.assign(d->images, d->images + d->n_images);
         f.image_bytes.assign(d->image_bytes, d->image_bytes + d->n_image_bytes);
         f.perlins.assign(d->perlins, d->perlins + d->n_perlins);
+        stage("tables");
         if ((rc = build_primitives())) return rc;
+        stage("primitives");
+        start_early_fast_tree();
         if ((rc = compute_bounds())) return rc;
+        stage("bounds");
         if (d->world < 0 || (uint64_t)d->world >= d->n_objects) return fail(RT_E_INVALID, "world: object id out of range");
         if ((rc = flatten_object(d->world, 0, f.world))) return rc;
         f.world_bounds = f.object_bounds[d->world];
+        stage("object graph + BVHs");
         // lights (camera.rs:81; hittable_list.rs:67-81, quad.rs:117-136, sphere.rs:117-141)
         if (d->lights >= 0) {
             if ((uint64_t)d->lights >= d->n_objects) return fail(RT_E_INVALID, "lights: object id out of range");
@@ -946,11 +996,24 @@ struct Flattener {
             if (int rc2 = hoist_first_member(hoisted_root)) return rc2;
         // 4-wide copies of every BVH that holds no constant medium and has finite bounds (ordered traversal)
         f.qnodes.reserve(f.nodes.size() / 2 + 16);
+        // the BVH the primitive-BVH kernel will walk, if any: the world itself, or the one gathered from all its members
+        int64_t fast_candidate = -1;
+        {
+            uint32_t r = f.world;
+            if (RT_REF_KIND(r) == RT_REF_LIST && f.lists[RT_REF_INDEX(r)].count == 1) r = f.list_items[f.lists[RT_REF_INDEX(r)].first];
+            auto it = bvh_prim_only.find(r);
+            if (RT_REF_KIND(r) == RT_REF_NODE && it != bvh_prim_only.end() && it->second) fast_candidate = (int64_t)RT_REF_INDEX(r);
+            else if (hoisted_root >= 0 && hoist_whole_world) fast_candidate = hoisted_root;
+        }
         for (uint32_t root : bvh_roots) {
             const DNode& n = f.nodes[root];
             bool ok = !(n.flags & 1u);
             for (double v : n.bounds) ok = ok && std::isfinite(v);
             if (!ok) continue;
+            if ((int64_t)root == fast_candidate) { // a mesh gets a tree built for the nearest-first traversal instead of the collapse
+                if (int rcf = traversal_only_tree(root)) return rcf;
+                if (f.fast_tree) continue;
+            }
             if (f.qnodes.size() & 1u) add_empty_qnode();
             const uint32_t me = (uint32_t)f.qnodes.size();
             add_empty_qnode();
@@ -966,6 +1029,7 @@ struct Flattener {
             f.q_extent *= 1.0000001f;
         };
         measure_extent();
+        stage("4-wide trees");
         {
             uint32_t r = f.world;
             if (RT_REF_KIND(r) == RT_REF_LIST && f.lists[RT_REF_INDEX(r)].count == 1) r = f.list_items[f.lists[RT_REF_INDEX(r)].first];
@@ -974,9 +1038,8 @@ struct Flattener {
                 // the world is one BVH over primitives: the dedicated kernel traverses its 4-wide copy
                 f.fast_root = make_ref(REF_QNODE, f.wnodes[RT_REF_INDEX(r)].qroot - 1);
                 f.fast_stack = (uint32_t)need_q[RT_REF_INDEX(r)] + 1;
-                if (int rcf = traversal_only_tree(RT_REF_INDEX(r))) return rcf;
-                measure_extent();
                 f.quant_inflation = quantise_qnodes();
+                stage("8-bit boxes");
                 if (f.quant_inflation > 1.25) f.cqnodes.clear();
             }
         }
@@ -984,8 +1047,6 @@ struct Flattener {
             f.fast_root = make_ref(REF_QNODE, f.wnodes[(size_t)hoisted_root].qroot - 1);
             f.fast_stack = (uint32_t)need_q[(uint32_t)hoisted_root] + 1;
             if (hoist_whole_world) { // as if the world were that one BVH
-                if (int rcf = traversal_only_tree((uint32_t)hoisted_root)) return rcf;
-                measure_extent();
                 f.quant_inflation = quantise_qnodes();
                 if (f.quant_inflation > 1.25) f.cqnodes.clear();
             } else {
@@ -996,6 +1057,7 @@ struct Flattener {
             }
         }
         pack_fast_tree();
+        stage("packed tree");
         need_node.assign(f.nodes.size(), -1);
         f.max_stack = (uint32_t)need(f.world) + 1;
         if (f.max_stack > (uint32_t)STACK_MAX) {

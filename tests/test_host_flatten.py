@@ -171,7 +171,7 @@ def _walk_packed_beside_wide(s, n_tris):
     packed, overlap = s.packed_nodes()
     root, refs, only = s.fast_tree_info()
     assert len(packed) > n_tris // 4 and wide[root]["has_box8"] == 1
-    assert len(packed) < len(wide)  # dense: the 64-byte array keeps padding nodes (and the reference tree's collapse)
+    assert len(packed) <= len(wide)  # dense: the collapse of the reference tree keeps padding nodes in the 64-byte array
     seen = np.zeros(n_tris, dtype=int)
     leaf_area = 0.0
     todo = [(root, 0)]
@@ -348,7 +348,10 @@ def _check_wide_tree(wn, leaf_points):
     return seen
 
 
-def test_wide_nodes_contain_their_children():
+def test_wide_nodes_contain_their_children(monkeypatch):
+    """The 4-wide collapse of the reference's tree (a mesh of 1024 triangles or more is normally walked through the
+    traversal-only tree, whose leaves may hold parts of triangles: test_traversal_only_tree_covers_every_point_of_every_triangle)."""
+    monkeypatch.setenv("MI355RT_FAST_TREE_MIN", "0")
     tris = scenes.triangle_soup(3000, seed=5)
     desc = rt.SceneDesc.from_world(rt.Mesh(tris, rt.Lambertian(rt.Color(.5, .5, .5))))
     wn = rt.Scene(desc, host_only=True).wide_nodes()
