@@ -125,7 +125,11 @@ RT_DEV float ubyte_f32(uint32_t w, int byte) { return (float)((w >> (8 * byte)) 
 // carries the ray's index in the caller's batch, where the result goes.
 // Launch bound: the packed variant on prepared rays is held to 80 vector registers (it needs 81 unbounded), which
 // lets a sixth wave per SIMD in without spilling; the other variants would spill and stay as they compile.
-template <int PRIM, bool COUNT, int FMT, int RS, bool PREP>
+// EXACT: RT_HIT_EXACT_CULL.  The tree is the collapse of the reference's own, and a child whose conservative
+// box the ray enters is only taken when Aabb::hit (aabb.rs:82-107, f64, `max <= min` culls) also passes on the box
+// the reference would test last on its way to that child, with the interval [tmin, closest hit so far]: a box the
+// ray merely touches is culled as the reference culls it.
+template <int PRIM, bool COUNT, int FMT, int RS, bool PREP, bool EXACT = false>
 __global__ __launch_bounds__(FAST_BLOCK, (FMT == NODES_PACKED && PREP && !COUNT) ? 6 : 1) void bvh4_closest_hit_kernel(DScene S, uint32_t root, rt_ray_batch rays,
                                                                        unsigned long long n_in, RayQueue rq, uint32_t opt, double tmin_default,
                                                                        float scene_extent, double* out_t, uint32_t* out_prim,
@@ -134,6 +138,7 @@ __global__ __launch_bounds__(FAST_BLOCK, (FMT == NODES_PACKED && PREP && !COUNT)
                                                                        int leaf_vote, int chunk_in, int postpone_leaves, const PRay* prep) {
     constexpr bool QUANT = FMT != NODES_F32, PACKED = FMT == NODES_PACKED;
     static_assert(!PACKED || PRIM == RT_REF_TRI, "the packed tree holds triangles only");
+    static_assert(!EXACT || FMT != NODES_PACKED, "the exact-cull tree is walked on its 64-byte or f32 nodes");
     constexpr unsigned long long OUT_T_STRIDE = RS, OUT_PRIM_STRIDE = RS == 1 ? 1 : 2 * RS;
     __shared__ uint2 s_fast_stack[LDS_STACK * FAST_BLOCK];
     LaneStack st;
@@ -244,6 +249,7 @@ __global__ __launch_bounds__(FAST_BLOCK, (FMT == NODES_PACKED && PREP && !COUNT)
                             r.dx = p.d[0]; r.dy = p.d[1]; r.dz = p.d[2];
 #pragma unroll
                             for (int k = 0; k < 3; ++k) { q.inv[k] = p.inv[k]; q.cn[k] = p.cn[k]; q.cf[k] = p.cf[k]; q.neg[k] = (p.neg >> k) & 1u; }
+                            if (EXACT) set_inverse(r); // Aabb::hit's 1 / d (aabb.rs:88)
                             time = p.time; tmin = p.tmin; best_t = p.tmax;
                             tmin32 = p.tmin32; best32 = p.tmax32;
                             best_ref = RT_REF_NONE;
@@ -396,7 +402,8 @@ __global__ __launch_bounds__(FAST_BLOCK, (FMT == NODES_PACKED && PREP && !COUNT)
                 for (int j = 0; j < 4; ++j) {
                     const float tn = fmaxf(fmaxf(__builtin_fmaf(nx[j], ax, bnx), __builtin_fmaf(ny[j], ay, bny)), fmaxf(__builtin_fmaf(nz[j], az, bnz), tmin32));
                     const float tf = fminf(fminf(__builtin_fmaf(fx[j], ax, bfx), __builtin_fmaf(fy[j], ay, bfy)), fminf(__builtin_fmaf(fz[j], az, bfz), best32));
-                    const bool hit = (tn <= tf) && (rf[j] != RT_REF_NONE);
+                    bool hit = (tn <= tf) && (rf[j] != RT_REF_NONE);
+                    if (EXACT && hit) hit = slab_test(S.ebox + ((size_t)((cur & 0x0FFFFFFFu) - S.exact_first) * 4u + (size_t)j) * 6u, r, tmin, best_t);
                     key[j] = hit ? tn : __builtin_inff();
                     if (COUNT) nn += rf[j] != RT_REF_NONE ? 1u : 0u;
                 }

@@ -550,18 +550,30 @@ struct Flattener {
     // several children of a node finds the later ones in a line it has already pulled in.
     // Returns the stack entries a traversal below this node can need.
     std::vector<uint8_t> qdepth; // depth of every 4-wide node below the root of its tree
+    // exact_boxes != nullptr: also record, for every child, the f64 box the reference tests last on its way to that
+    // child -- the child's own node box for an inner child, the box of the binary node that holds it for a primitive
+    // (the reference tests node boxes only, bvh.rs:118-140; a primitive is tested whenever its node's box passes).
+    // Entry ((wide node - exact_base) * 4 + slot) * 6 of *exact_boxes, for the traversal that culls exactly like Aabb::hit.
+    std::vector<double>* exact_boxes = nullptr;
+    uint32_t exact_base = 0;
     int32_t fill_qnode(uint32_t me, uint32_t idx, int depth) {
         qdepth[me] = (uint8_t)std::min(depth, 255);
         uint32_t refs[4];
         float boxes[4][6];
+        const double* path_box[4] = {nullptr, nullptr, nullptr, nullptr};
         int n = 0;
-        auto add = [&](uint32_t ref, const float* b) { refs[n] = ref; for (int k = 0; k < 6; ++k) boxes[n][k] = b[k]; ++n; };
+        auto add = [&](uint32_t ref, const float* b, uint32_t holder) {
+            refs[n] = ref;
+            for (int k = 0; k < 6; ++k) boxes[n][k] = b[k];
+            path_box[n] = RT_REF_KIND(ref) == RT_REF_NODE ? f.nodes[RT_REF_INDEX(ref)].bounds : f.nodes[holder].bounds;
+            ++n;
+        };
         auto expand = [&](uint32_t ref, const float* b) {
             if (RT_REF_KIND(ref) == RT_REF_NODE) {
                 const WNode& c = f.wnodes[RT_REF_INDEX(ref)];
-                add(c.left, c.lb);
-                if (!(c.meta & 2u)) add(c.right, c.rb);
-            } else add(ref, b);
+                add(c.left, c.lb, RT_REF_INDEX(ref));
+                if (!(c.meta & 2u)) add(c.right, c.rb, RT_REF_INDEX(ref));
+            } else add(ref, b, idx);
         };
         {
             const WNode w = f.wnodes[idx];
@@ -575,6 +587,12 @@ struct Flattener {
             if (f.qnodes.size() & 1u) add_empty_qnode(); // pad: sibling groups start on a line boundary
             base = (uint32_t)f.qnodes.size();
             for (int k = 0; k < n_inner; ++k) add_empty_qnode();
+        }
+        if (exact_boxes) {
+            const size_t at = (size_t)(me - exact_base) * 24;
+            if (exact_boxes->size() < at + 24) exact_boxes->resize(std::max(at + 24, (size_t)(f.qnodes.size() - exact_base) * 24), 0.0);
+            for (int j = 0; j < n; ++j)
+                for (int k = 0; k < 6; ++k) (*exact_boxes)[at + (size_t)j * 6 + k] = path_box[j][k];
         }
         int32_t deepest = 0;
         uint32_t out_refs[4] = {RT_REF_NONE, RT_REF_NONE, RT_REF_NONE, RT_REF_NONE};
@@ -597,6 +615,38 @@ struct Flattener {
             }
         }
         return (n - 1) + deepest; // up to n-1 siblings stay on the stack while one child is traversed
+    }
+    // The tree of RT_HIT_ORDERED | RT_HIT_EXACT_CULL for a world that is one BVH over primitives: the 4-wide collapse of
+    // the reference's tree once more, with the exact boxes beside it, under a root node of its own whose single child is
+    // the BVH's root (so that the root's box is tested like every other).
+    int exact_cull_tree(uint32_t root) {
+        if (f.qnodes.size() & 1u) add_empty_qnode();
+        f.exact_first = (uint32_t)f.qnodes.size();
+        const uint32_t top = f.exact_first;
+        add_empty_qnode();
+        add_empty_qnode(); // (keeps the BVH root's own sibling group on an even index)
+        const uint32_t me = (uint32_t)f.qnodes.size();
+        add_empty_qnode();
+        f.ebox.clear();
+        exact_boxes = &f.ebox;
+        exact_base = f.exact_first;
+        const int32_t need = fill_qnode(me, root, 1);
+        exact_boxes = nullptr;
+        f.ebox.resize((size_t)(f.qnodes.size() - f.exact_first) * 24, 0.0);
+        QNode& q = f.qnodes[top];
+        q.child[0] = make_ref(REF_QNODE, me);
+        widen_box(f.nodes[root].bounds, q, 0);
+        for (int k = 0; k < 6; ++k) f.ebox[k] = f.nodes[root].bounds[k];
+        qdepth[top] = 0;
+        f.exact_root = make_ref(REF_QNODE, top);
+        f.exact_stack = (uint32_t)need + 2;
+        f.exact_count = (uint32_t)f.qnodes.size() - f.exact_first;
+        return RT_OK;
+    }
+    void widen_box(const double* b, QNode& q, int j) {
+        float o[6];
+        widen(b, o);
+        for (int a = 0; a < 3; ++a) { q.lo[a][j] = o[2 * a]; q.hi[a][j] = o[2 * a + 1]; }
     }
     // The renderer's primitive-BVH kernel is several times faster per ray than the general traversal, but it only
     // walks a BVH whose leaves are primitives.  When the world is a list whose FIRST member is a BVH without
@@ -722,6 +772,7 @@ struct Flattener {
         f.fast_root = make_ref(REF_QNODE, res.root);
         f.fast_stack = (uint32_t)res.stack_need + 1;
         f.fast_tree = true;
+        fast_tree_count = (size_t)res.wide_nodes;
         fast_ratio_sum = res.ratio_sum; fast_ratio_n = res.ratio_n;
         fast_leaf_area = res.leaf_area;
         // the general kernel's nearest-first traversal enters the same tree at this BVH's root
@@ -759,7 +810,7 @@ struct Flattener {
             return build_fast_tree(f.tris.data(), early.scene, early.depth, early.ids.data(), early.ids.size(), early.res, early.err);
         });
     }
-    size_t fast_tree_first = 0;   // first of the traversal-only tree's nodes in qnodes (they come with their 8-bit and packed forms)
+    size_t fast_tree_first = 0, fast_tree_count = 0; // the traversal-only tree's nodes in qnodes (they come with their 8-bit and packed forms)
     double fast_ratio_sum = 0.0, fast_leaf_area = 0.0;
     uint64_t fast_ratio_n = 0;
 
@@ -795,8 +846,9 @@ struct Flattener {
         f.cqnodes.resize(f.qnodes.size()); // (the traversal-only tree has brought its 8-bit nodes along: fast_tree.cpp)
         double ratio_sum = fast_ratio_sum;
         uint64_t ratio_n = fast_ratio_n;
-        const size_t limit = f.fast_tree ? fast_tree_first : f.qnodes.size();
-        for (size_t i = 0; i < limit; ++i) {
+        const size_t fast_end = f.fast_tree ? fast_tree_first + fast_tree_count : 0;
+        for (size_t i = 0; i < f.qnodes.size(); ++i) {
+            if (f.fast_tree && i >= fast_tree_first && i < fast_end) continue;          // came with their 8-bit form
             quantise_node(f.qnodes[i], f.cqnodes[i]);
             if (qdepth[i] < 4)
                 for (int j = 0; j < 4; ++j) {
@@ -1010,15 +1062,22 @@ struct Flattener {
             bool ok = !(n.flags & 1u);
             for (double v : n.bounds) ok = ok && std::isfinite(v);
             if (!ok) continue;
-            if ((int64_t)root == fast_candidate) { // a mesh gets a tree built for the nearest-first traversal instead of the collapse
+            if ((int64_t)root == fast_candidate) {
+                // a mesh gets a tree built for the nearest-first traversal instead of the collapse (first: a tree that was
+                // built beside the reference BVHs brings its arrays along as the scene's first wide nodes)
                 if (int rcf = traversal_only_tree(root)) return rcf;
-                if (f.fast_tree) continue;
+                if (f.fast_tree) {
+                    if (int rce = exact_cull_tree(root)) return rce;
+                    continue;
+                }
             }
             if (f.qnodes.size() & 1u) add_empty_qnode();
             const uint32_t me = (uint32_t)f.qnodes.size();
             add_empty_qnode();
             need_q[root] = fill_qnode(me, root, 0);
             f.wnodes[root].qroot = me + 1;
+            if ((int64_t)root == fast_candidate)
+                if (int rce = exact_cull_tree(root)) return rce;
         }
         auto measure_extent = [&]() {
             f.q_extent = 0.0f;

@@ -43,6 +43,11 @@ struct FlatScene {
     uint32_t max_stack = 0;
     uint32_t fast_root = RT_REF_NONE; // set when the world is one BVH whose leaves are all primitives
     uint32_t fast_stack = 0;          // stack entries the primitive-BVH kernel needs
+    // RT_HIT_ORDERED | RT_HIT_EXACT_CULL on such a world: the collapse of the reference's tree (wide nodes exact_first ..
+    // exact_first + exact_count of qnodes, entered at exact_root) and, per node and slot, the f64 box Aabb::hit is
+    // evaluated on before that child is entered (ebox: 6 doubles per slot, 24 per node, indexed from exact_first)
+    std::vector<double> ebox;
+    uint32_t exact_root = RT_REF_NONE, exact_first = 0, exact_count = 0, exact_stack = 0;
     bool fast_tree = false;           // fast_root is a traversal-only tree (fast_tree.cpp): leaves may name a triangle more than once, with partial boxes
     bool fast_partial = false;        // fast_root covers only the FIRST member of the world list (rebuilt as one BVH over its
                                       // primitives); `world_rest` is the list of the remaining members, traversed afterwards

@@ -177,6 +177,16 @@ template <int RS, bool PREP> FastKernel fast_kernel_pick(int prim, bool count, i
 }
 FastKernel fast_kernel(int prim, bool count, int fmt) { return fast_kernel_pick<1, false>(prim, count, fmt); }          // structure-of-arrays batches of the C ABI
 FastKernel fast_kernel_prepared(int prim, bool count, int fmt) { return fast_kernel_pick<1, true>(prim, count, fmt); }  // batches binned and prepared by the reorder pass
+template <int FMT, bool PREP> FastKernel fast_kernel_exact_for(int prim, bool count) {
+    if (prim == (int)RT_REF_TRI) return count ? bvh4_closest_hit_kernel<RT_REF_TRI, true, FMT, 1, PREP, true> : bvh4_closest_hit_kernel<RT_REF_TRI, false, FMT, 1, PREP, true>;
+    if (prim == (int)RT_REF_SPHERE) return count ? bvh4_closest_hit_kernel<RT_REF_SPHERE, true, FMT, 1, PREP, true> : bvh4_closest_hit_kernel<RT_REF_SPHERE, false, FMT, 1, PREP, true>;
+    return count ? bvh4_closest_hit_kernel<0, true, FMT, 1, PREP, true> : bvh4_closest_hit_kernel<0, false, FMT, 1, PREP, true>;
+}
+// RT_HIT_EXACT_CULL: the collapse of the reference's tree (64-byte nodes with 8-bit boxes, or f32 nodes) + exact boxes
+FastKernel fast_kernel_exact(int prim, bool count, int fmt, bool prepared) {
+    if (fmt == NODES_8BIT) return prepared ? fast_kernel_exact_for<NODES_8BIT, true>(prim, count) : fast_kernel_exact_for<NODES_8BIT, false>(prim, count);
+    return prepared ? fast_kernel_exact_for<NODES_F32, true>(prim, count) : fast_kernel_exact_for<NODES_F32, false>(prim, count);
+}
 FastKernel fast_kernel_paths(int prim, int fmt) { return fast_kernel_pick<(int)PATH_DOUBLES, false>(prim, false, fmt); } // strided views of the renderer's path records
 int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
@@ -192,6 +202,7 @@ Tuning read_tuning() {
     t.prep_refill = env_int("MI355RT_PREP_REFILL", PREP_REFILL_THRESHOLD);
     t.prep_vote = env_int("MI355RT_PREP_VOTE", PREP_LEAF_VOTE);
     t.quant = env_int("MI355RT_QUANT", 1) != 0;
+    t.exact_fast = env_int("MI355RT_EXACT_FAST", 1) != 0;
     t.fast_extend = env_int("MI355RT_FAST_EXTEND", 1) != 0;
     t.shade_textures = env_int("MI355RT_SHADE_TEXTURES", 0) != 0;
     t.reorder = env_int("MI355RT_REORDER", 1);
@@ -255,7 +266,7 @@ int pick_grid(rt_scene* s) {
         if (s->tune.fast_blocks_per_cu > 0) prep_per_cu = std::min(prep_per_cu, s->tune.fast_blocks_per_cu);
         s->fast_grid_blocks_prep = prop.multiProcessorCount * std::max(1, prep_per_cu);
         {
-            size_t entries = (size_t)std::max<uint32_t>(s->flat.fast_stack, 1u);
+            size_t entries = (size_t)std::max<uint32_t>(std::max(s->flat.fast_stack, s->flat.exact_stack), 1u);
             size_t bytes = entries * (size_t)std::max(s->fast_grid_blocks, s->fast_grid_blocks_prep) * FAST_BLOCK * sizeof(uint2);
             void* p = nullptr;
             HIP_TRY(hipMalloc(&p, bytes));
@@ -275,6 +286,7 @@ void fill_host_dscene(rt_scene* s) {
     d.media = f.media.data(); d.materials = f.materials.data(); d.textures = f.textures.data(); d.images = f.images.data();
     d.image_bytes = f.image_bytes.data(); d.perlins = f.perlins.data(); d.lights = f.lights.data();
     d.world = f.world; d.n_lights = f.n_lights; d.lights_is_list = f.lights_is_list; d.q_extent = f.q_extent; d.uses_uv = f.uses_uv ? 1u : 0u; d.world_rest = f.world_rest;
+    d.ebox = f.ebox.data(); d.exact_first = f.exact_first;
 }
 
 int upload_scene(rt_scene* s) {
@@ -311,6 +323,8 @@ int upload_scene(rt_scene* s) {
     if ((rc = upload(s, f.image_bytes, &d.image_bytes))) return rc;
     if ((rc = upload(s, f.perlins, &d.perlins))) return rc;
     if ((rc = upload(s, f.lights, &d.lights))) return rc;
+    if ((rc = upload(s, f.ebox, &d.ebox))) return rc;
+    d.exact_first = f.exact_first;
     d.world = f.world; d.n_lights = f.n_lights; d.lights_is_list = f.lights_is_list; d.q_extent = f.q_extent; d.uses_uv = f.uses_uv ? 1u : 0u; d.world_rest = f.world_rest;
     void* c = nullptr;
     HIP_TRY(hipMalloc(&c, C_ALLOC * sizeof(unsigned long long)));
@@ -413,7 +427,10 @@ int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit
     const bool exact_cull = (flags & RT_HIT_ORDERED) && (flags & RT_HIT_EXACT_CULL);
     const bool count = flags & RT_HIT_COUNTERS, ordered = (flags & RT_HIT_ORDERED) && !exact_cull;
     const Tuning& tn = s->tune;
-    if (ordered && s->flat.fast_root != RT_REF_NONE && !s->flat.fast_partial) {
+    // ... of a world that is one BVH over primitives: the primitive-BVH kernel on the collapse of the reference's tree, every
+    // child confirmed on its exact box (MI355RT_EXACT_FAST=0 keeps the general kernel, for A/B measurements)
+    const bool exact_fast = exact_cull && s->flat.exact_root != RT_REF_NONE && s->flat.fast_root != RT_REF_NONE && !s->flat.fast_partial && tn.exact_fast;
+    if ((ordered || exact_fast) && s->flat.fast_root != RT_REF_NONE && !s->flat.fast_partial) {
         // the world is one BVH over primitives: dedicated traversal kernel + one pass that completes the records
         int fblocks = (int)std::min<uint64_t>((uint64_t)s->fast_grid_blocks, (waves + (FAST_BLOCK / 64) - 1) / (FAST_BLOCK / 64));
         RayQueue rq{nullptr, nullptr};
@@ -438,21 +455,21 @@ int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit
             hipLaunchKernelGGL(reorder_count_kernel, dim3(cblocks), dim3(REORDER_BLOCK), 0, st, *rays, (unsigned long long)n, s->grid, s->prep_bins, s->prep_hist);
             hipLaunchKernelGGL(reorder_scan_kernel, dim3(1), dim3(1024), 0, st, s->prep_hist, s->prep_cursor);
             // (the packed tree takes 64-byte records; it is not used when the batch brings lower ends of its own, see below)
-            hipLaunchKernelGGL((s->fast_fmt == NODES_PACKED && !(opt & 2u)) ? reorder_scatter_kernel<true> : reorder_scatter_kernel<false>,
+            hipLaunchKernelGGL((s->fast_fmt == NODES_PACKED && !(opt & 2u) && !exact_fast) ? reorder_scatter_kernel<true> : reorder_scatter_kernel<false>,
                                dim3((unsigned)((n + REORDER_TILE - 1) / REORDER_TILE)), dim3(SCATTER_BLOCK), 0, st, *rays,
                                (unsigned long long)n, opt, 0.001, s->fast_extent, (const uint16_t*)s->prep_bins, s->prep_cursor, s->prep);
             HIP_TRY(hipGetLastError());
         }
         RT_EVENT(ev[1]);
         // the packed nodes order children by keys that need entry distances >= 0, i.e. tmin >= 0: certain only for the default tmin
-        const int fmt = (s->fast_fmt == NODES_PACKED && (opt & 2u)) ? NODES_8BIT : s->fast_fmt;
-        const uint32_t entry = fmt == s->fast_fmt ? s->fast_entry : s->flat.fast_root;
+        const int fmt = exact_fast ? (s->fast_fmt == NODES_F32 ? NODES_F32 : NODES_8BIT) : ((s->fast_fmt == NODES_PACKED && (opt & 2u)) ? NODES_8BIT : s->fast_fmt);
+        const uint32_t entry = exact_fast ? s->flat.exact_root : (fmt == s->fast_fmt ? s->fast_entry : s->flat.fast_root);
         // lanes go on past a primitive they have reached where a ray crosses many triangle boxes (bvh_kernel.h);
         // measured on reordered batches: the 2^20-triangle soup (overlap 70) gains 3 %, a closed surface of 1.3 M triangles
         // (overlap 3.9) loses 3 %; on batches traced as they come closed surfaces of 82 k and 1.3 M triangles gain 1-3 %
         const int postpone = tn.postpone >= 0 ? tn.postpone : (fmt == NODES_PACKED && (!reorder || s->flat.fast_leaf_overlap > POSTPONE_MIN_OVERLAP) ? 1 : 0);
         const int refill = reorder ? tn.prep_refill : (tn.refill >= 0 ? tn.refill : HIT_REFILL_THRESHOLD), vote = reorder ? tn.prep_vote : (tn.vote >= 0 ? tn.vote : HIT_LEAF_VOTE);
-        const FastKernel kernel = reorder ? fast_kernel_prepared(s->fast_prim, count, fmt) : fast_kernel(s->fast_prim, count, fmt);
+        const FastKernel kernel = exact_fast ? fast_kernel_exact(s->fast_prim, count, fmt, reorder) : (reorder ? fast_kernel_prepared(s->fast_prim, count, fmt) : fast_kernel(s->fast_prim, count, fmt));
         if (count) { // the counting variants have more registers than the grids are sized for: every workgroup of a launch must be resident
             int per_cu = 0, cus = 0;
             HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, FAST_BLOCK, 0));
@@ -739,7 +756,7 @@ int rt_scene_get_wide_nodes(const rt_scene* s, uint64_t first, uint64_t count, r
                 o.box8[j][2 * a] = o.box8[j][2 * a + 1] = 0.0;
             }
         }
-        if (has8) {
+        if (o.has_box8) {
             const CQNode& c = s->flat.cqnodes[first + i];
             for (int a = 0; a < 3; ++a) {
                 const double step = std::ldexp(1.0, (int)c.exp[a] - 127);

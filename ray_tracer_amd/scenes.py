@@ -144,14 +144,17 @@ def quads() -> SceneTuple:  # main.rs:305-366
     return world_bvh, None, _sky_camera(80.0, Point3(0.0, 0.0, 9.0), Point3(0.0, 0.0, 0.0), aspect=1.0)
 
 
-def simple_light(seed: int = 0) -> SceneTuple:  # main.rs:368-419
+def simple_light(seed: int = 0, sphere_light: bool = True) -> SceneTuple:  # main.rs:368-419
+    """`sphere_light` = False: the scene one step earlier in the reference's history, lit by the rectangle alone
+    (time_record.txt:15, output29.ppm); with the sphere above it is the scene as it stands (output30.ppm)."""
     rtweekend.seed(seed)
     world = HittableList()
     mat = Lambertian.from_texture(NoiseTexture(4.0))
     world.add(Sphere(Point3(0.0, -1000.0, 0.0), 1000.0, mat))
     world.add(Sphere(Point3(0.0, 2.0, 0.0), 2.0, mat))
     difflight = DiffuseLight.from_color(Color(4.0, 4.0, 4.0))
-    world.add(Sphere(Point3(0.0, 7.0, 0.0), 2.0, difflight))
+    if sphere_light:
+        world.add(Sphere(Point3(0.0, 7.0, 0.0), 2.0, difflight))
     world.add(Quad(Point3(3.0, 1.0, -2.0), Vec3(2.0, 0.0, 0.0), Vec3(0.0, 2.0, 0.0), difflight))
     cam = _sky_camera(20.0, Point3(26.0, 3.0, 6.0), Point3(0.0, 2.0, 0.0))
     cam.background = Color(0.0, 0.0, 0.0)
@@ -195,10 +198,12 @@ def cornell_box(image_width: int = 600, samples_per_pixel: int = 1000, max_depth
     return world, lights, cam
 
 
-def cornell_two_blocks(image_width: int = 600, samples_per_pixel: int = 200, max_depth: int = 50) -> SceneTuple:
-    """The "standard Cornell box scene" of Book 2 (the revision of main.rs that rendered output33.ppm, see
-    time_record.txt:19): the room of cornell_box with two rotated blocks and no glass sphere, rendered before the
-    light list existed (material PDF alone: lights = None)."""
+def cornell_two_blocks(image_width: int = 600, samples_per_pixel: int = 200, max_depth: int = 50, blocks: str = "rotated") -> SceneTuple:
+    """The Cornell box of Book 2 as the reference's history rendered it, before the light list existed (material PDF
+    alone: lights = None).  blocks = "rotated": the "standard Cornell box scene" (output33.ppm, time_record.txt:19), the
+    room of cornell_box with two rotated blocks and no glass sphere; "axis": the step before, the same two blocks not
+    yet rotated ("Cornell box with two blocks", output32.ppm, time_record.txt:18); "none": the empty room
+    (output31.ppm, time_record.txt:17)."""
     world = HittableList()
     red = Lambertian(Color(0.65, 0.05, 0.05))
     white = Lambertian(Color(0.73, 0.73, 0.73))
@@ -210,10 +215,16 @@ def cornell_two_blocks(image_width: int = 600, samples_per_pixel: int = 200, max
     world.add(Quad(Point3(0.0, 0.0, 0.0), Vec3(555.0, 0.0, 0.0), Vec3(0.0, 0.0, 555.0), white))
     world.add(Quad(Point3(555.0, 555.0, 555.0), Vec3(-555.0, 0.0, 0.0), Vec3(0.0, 0.0, -555.0), white))
     world.add(Quad(Point3(0.0, 0.0, 555.0), Vec3(555.0, 0.0, 0.0), Vec3(0.0, 555.0, 0.0), white))
-    box1: Hittable = box_new(Point3(0.0, 0.0, 0.0), Point3(165.0, 330.0, 165.0), white)
-    world.add(Translate(RotateY(box1, 15.0), Vec3(265.0, 0.0, 295.0)))
-    box2: Hittable = box_new(Point3(0.0, 0.0, 0.0), Point3(165.0, 165.0, 165.0), white)
-    world.add(Translate(RotateY(box2, -18.0), Vec3(130.0, 0.0, 65.0)))
+    if blocks == "rotated":
+        box1: Hittable = box_new(Point3(0.0, 0.0, 0.0), Point3(165.0, 330.0, 165.0), white)
+        world.add(Translate(RotateY(box1, 15.0), Vec3(265.0, 0.0, 295.0)))
+        box2: Hittable = box_new(Point3(0.0, 0.0, 0.0), Point3(165.0, 165.0, 165.0), white)
+        world.add(Translate(RotateY(box2, -18.0), Vec3(130.0, 0.0, 65.0)))
+    elif blocks == "axis":
+        world.add(box_new(Point3(130.0, 0.0, 65.0), Point3(295.0, 165.0, 230.0), white))
+        world.add(box_new(Point3(265.0, 0.0, 295.0), Point3(430.0, 330.0, 460.0), white))
+    elif blocks != "none":
+        raise ValueError(blocks)
     cam = _cornell_camera(samples_per_pixel)
     cam.image_width, cam.max_depth = image_width, max_depth
     return world, None, cam

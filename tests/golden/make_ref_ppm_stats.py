@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Statistics of the rendered images the reference ships (its only result artefacts): overall mean RGB and the
-means of an 8 x 8 grid of blocks, of output28.ppm (quads, 400 x 400), output33.ppm (standard Cornell box,
-600 x 600), output34.ppm (Cornell box with blocks of smoke) and output35.ppm (Book-2 final scene, simple settings, 400 x 400).  Only numbers derived from the
+means of an 8 x 8 grid of blocks, of thirteen of them (FILES below: output13, 16, 18, 19, 27-35.ppm, the ones
+whose scenes ray_tracer_amd/scenes.py rebuilds).  Only numbers derived from the
 pixel data are written (tests/golden/ref_ppm_stats.json); run in the build container, where /root/reference
 exists:   python tests/golden/make_ref_ppm_stats.py
 
@@ -15,7 +15,13 @@ import os
 import numpy as np
 
 REF = "/root/reference"
-FILES = {"quads": "output28.ppm", "cornell_two_blocks": "output33.ppm", "cornell_smoke": "output34.ppm", "book2_final_simple": "output35.ppm"}
+FILES = {"quads": "output28.ppm", "cornell_two_blocks": "output33.ppm", "cornell_smoke": "output34.ppm", "book2_final_simple": "output35.ppm",
+         # Book 1 / early Book 2, rendered under the sky gradient (400 x 225)
+         "five_spheres": "output13.ppm", "bouncing_spheres": "output16.ppm", "bouncing_spheres_checker_ground": "output18.ppm",
+         "checkered_spheres": "output19.ppm", "perlin_marble": "output27.ppm",
+         # Book 2, black background
+         "simple_light_rectangle": "output29.ppm", "simple_light_rectangle_and_sphere": "output30.ppm",
+         "cornell_empty": "output31.ppm", "cornell_axis_blocks": "output32.ppm"}
 
 
 def read_p3(path):
