@@ -183,6 +183,8 @@ struct DScene {
     float q_extent;            // largest |coordinate| stored in the 4-wide nodes (margin of the f32 slab test)
     uint32_t uses_uv;          // some texture reads the surface coordinates u,v (an image texture exists)
     uint32_t world_rest;       // the world list without its first member (RT_REF_NONE unless that member is traced by the primitive-BVH kernel)
+    uint32_t n_xforms;         // entries of `xforms`
+    uint32_t n_perlins;        // entries of `perlins`
     const double* ebox;        // exact-cull tree: per 4-wide node from exact_first on and slot, the f64 box Aabb::hit is evaluated on (6 doubles)
     uint32_t exact_first;
 };

@@ -287,6 +287,7 @@ void fill_host_dscene(rt_scene* s) {
     d.image_bytes = f.image_bytes.data(); d.perlins = f.perlins.data(); d.lights = f.lights.data();
     d.world = f.world; d.n_lights = f.n_lights; d.lights_is_list = f.lights_is_list; d.q_extent = f.q_extent; d.uses_uv = f.uses_uv ? 1u : 0u; d.world_rest = f.world_rest;
     d.ebox = f.ebox.data(); d.exact_first = f.exact_first;
+    d.n_xforms = (uint32_t)f.xforms.size(); d.n_perlins = (uint32_t)f.perlins.size();
 }
 
 int upload_scene(rt_scene* s) {
@@ -325,6 +326,7 @@ int upload_scene(rt_scene* s) {
     if ((rc = upload(s, f.lights, &d.lights))) return rc;
     if ((rc = upload(s, f.ebox, &d.ebox))) return rc;
     d.exact_first = f.exact_first;
+    d.n_xforms = (uint32_t)f.xforms.size(); d.n_perlins = (uint32_t)f.perlins.size();
     d.world = f.world; d.n_lights = f.n_lights; d.lights_is_list = f.lights_is_list; d.q_extent = f.q_extent; d.uses_uv = f.uses_uv ? 1u : 0u; d.world_rest = f.world_rest;
     void* c = nullptr;
     HIP_TRY(hipMalloc(&c, C_ALLOC * sizeof(unsigned long long)));
@@ -1017,6 +1019,17 @@ int rt_get_counters(rt_scene* s, rt_counters* out) {
         s->counters.render_rays = s->h_counters[C_RAYS];
         if (s->tune.debug) {
 #ifdef RT_PHASE_STATS
+            {
+                unsigned long long sec[72];
+                HIP_TRY(hipMemcpy(sec, s->d_counters + C_STATS, sizeof(sec), hipMemcpyDeviceToHost));
+                static const char* const names[24] = {"wave-load of paths", "finalize: ray into context", "finalize: record by kind", "finalize: transform unwinding",
+                    "material record", "metal", "dielectric", "lambert/iso: colour", "lambert/iso: mixture choice + light pick", "lambert/iso: two draws + sampler",
+                    "lambert/iso: pdf values (light tests)", "path record load", "shade_hit", "", "", "", "", "", "", "", "", "", "", ""};
+                for (int k = 0; k < 13; ++k)
+                    if (sec[24 + k])
+                        std::fprintf(stderr, "[mi355rt] shade section %-44s runs %12llu  lanes/run %5.1f  wave cycles %14llu\n", names[k], sec[24 + k],
+                                     (double)sec[k] / (double)sec[24 + k], sec[48 + k]);
+            }
             std::fprintf(stderr, "[mi355rt] shade wave cycles: record load %llu hit record %llu material %llu write-back %llu queue %llu\n", s->h_counters[24],
                          s->h_counters[25], s->h_counters[26], s->h_counters[27], s->h_counters[28]);
             std::fprintf(stderr, "[mi355rt] traversal loop iterations: sum over lanes %llu, wave maximum x active lanes %llu\n", s->h_counters[29], s->h_counters[30]);

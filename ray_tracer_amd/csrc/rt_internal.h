@@ -31,7 +31,7 @@ enum { C_WORK = 0, C_LIVE_IN = 1, C_LIVE_OUT = 2, C_NODES = 4, C_PRIMS = 5, C_RA
 // Work counters of the general persistent kernels: one per XCD, each on a 128-byte line of its own, behind the
 // C_WORDS statistics words.
 // (The primitive-BVH kernel is handed the first slot and addresses them as work_counter + (workgroup % 8) * 16.)
-constexpr int WORK_SLOTS = 8, WORK_STRIDE = 16, C_WORK_SLOTS = 32, C_ALLOC = C_WORK_SLOTS + WORK_SLOTS * WORK_STRIDE;
+constexpr int WORK_SLOTS = 8, WORK_STRIDE = 16, C_WORK_SLOTS = 32, C_STATS = C_WORK_SLOTS + WORK_SLOTS * WORK_STRIDE, C_ALLOC = C_STATS + 96; // (C_STATS: section statistics of the stats build)
 
 struct CamD { // Camera after initialize() (camera.rs:30-42)
     rt_camera_derived d;

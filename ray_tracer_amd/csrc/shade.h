@@ -225,7 +225,9 @@ RT_DEV D3 sample_lobe(const LobeSample& lobe, double r1, double r2) {
 // code in the kernel costs the textured shading kernel a wave per SIMD (264 instead of 243 registers).
 template <bool TEXTURES, bool RR>
 RT_DEV bool shade_hit(const DScene& S, const HitRec& h, D3 ray_dir, Rng& g, D3& beta, D3& L, D3& next_d) {
+    RT_SEC_BEGIN(4);
     const DMaterial m = S.materials[h.mat];
+    RT_SEC_END(4);
     if (m.kind == RT_MAT_DIFFUSE_LIGHT) { // material.rs:237-256: emits on the front face, never scatters
         // The back face emits black, and black still goes through the product: a path whose throughput is NaN
         // or infinite (a light-pdf of 0/0) makes the sample NaN in the recursion, so it must here too.
@@ -233,13 +235,16 @@ RT_DEV bool shade_hit(const DScene& S, const HitRec& h, D3 ray_dir, Rng& g, D3& 
         return false;
     }
     if (m.kind == RT_MAT_METAL) { // material.rs:135-158; skip_pdf branch camera.rs:276-295
+        RT_SEC_BEGIN(5);
         D3 reflected = reflect(ray_dir, h.normal);
         reflected = unit_vector(reflected) + m.fuzz * random_unit_vector(g);
         beta = beta * d3(m.albedo[0], m.albedo[1], m.albedo[2]);
         next_d = reflected;
+        RT_SEC_END(5);
         return true;
     }
     if (m.kind == RT_MAT_DIELECTRIC) { // material.rs:181-217
+        RT_SEC_BEGIN(6);
         double ri = h.front_face ? 1.0 / m.ior : m.ior;
         D3 unit_direction = unit_vector(ray_dir);
         double cos_theta = fmin(-dot(unit_direction, h.normal), 1.0);
@@ -257,11 +262,15 @@ RT_DEV bool shade_hit(const DScene& S, const HitRec& h, D3 ray_dir, Rng& g, D3& 
         D3 direction = do_reflect ? reflect(unit_direction, h.normal) : refract(unit_direction, h.normal, ri);
         beta = beta * d3(1.0, 1.0, 1.0);
         next_d = direction;
+        RT_SEC_END(6);
         return true;
     }
     // Lambertian (material.rs:77-117) / Isotropic (material.rs:278-300): sampled through a PDF
     const bool lambert = m.kind == RT_MAT_LAMBERTIAN;
+    RT_SEC_BEGIN(7);
     D3 attenuation = material_color<TEXTURES>(S, m, h.u, h.v, h.p);
+    RT_SEC_END(7);
+    RT_SEC_BEGIN(8);
     const D3 unit_normal = unit_vector(h.normal); // the w axis of CosinePdf's basis (pdf.rs:46-48, onb.rs:13); unused for Isotropic
     D3 dir = d3(1.0, 0.0, 0.0);
     bool from_light = false;
@@ -272,12 +281,16 @@ RT_DEV bool shade_hit(const DScene& S, const HitRec& h, D3 ray_dir, Rng& g, D3& 
     if (from_light) mode = lights_pick(S, h.p, g, dir, lobe);
     else if (lambert) mode = SAMPLE_LOBE;                              // pdf.rs:57-59
     else dir = random_unit_vector(g);                                  // pdf.rs:36-38
+    RT_SEC_END(8);
+    RT_SEC_BEGIN(9);
     if (mode != SAMPLE_DONE) {
         const double r1 = g.next();
         const double r2 = g.next();
         const D3 towards_quad = sample_quad(S, lobe.quad, mode == SAMPLE_QUAD, h.p, r1, r2);
         dir = mode == SAMPLE_QUAD ? towards_quad : sample_lobe(lobe, r1, r2);
     }
+    RT_SEC_END(9);
+    RT_SEC_BEGIN(10);
     double mat_pdf;
     if (lambert) { // CosinePdf::value (pdf.rs:52-55)
         double cosine_theta = dot(unit_vector(dir), unit_normal);
@@ -287,6 +300,7 @@ RT_DEV bool shade_hit(const DScene& S, const HitRec& h, D3 ray_dir, Rng& g, D3& 
     }
     double pdf_value = mat_pdf;
     if (S.n_lights >= 0) pdf_value = 0.5 * lights_pdf_value(S, h.p, dir) + 0.5 * mat_pdf; // pdf.rs:115-117
+    RT_SEC_END(10);
     double scattering_pdf;
     if (lambert) { // material.rs:110-117
         double cos_theta = dot(h.normal, unit_vector(dir));

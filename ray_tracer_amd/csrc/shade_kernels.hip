@@ -13,6 +13,8 @@ constexpr unsigned long long SHADE_GROUP = 4ull; // consecutive wave-loads a wav
 // second wave per SIMD, which it is worth a few spilled values to keep)
 template <bool TEXTURES, bool RR>
 __global__ __launch_bounds__(BLOCK, 2) void shade_kernel(DScene S, CamD cam, PathState ps, int qsel, unsigned long long seed, BatchGeom bg, int last_bounce) {
+    __shared__ DXform s_xforms[XF_LDS];
+    const XfTable xt = xf_fill_lds(S, s_xforms);
     const unsigned long long n = ps.counters[C_LIVE_IN];
     const uint32_t* qin = ps.queue[qsel];
     uint32_t* qout = ps.queue[qsel ^ 1];
@@ -32,6 +34,8 @@ __global__ __launch_bounds__(BLOCK, 2) void shade_kernel(DScene S, CamD cam, Pat
     const unsigned long long loads = (n + 63ull) / 64ull;
     const unsigned long long groups = (loads + SHADE_GROUP - 1ull) / SHADE_GROUP;
 #ifdef RT_PHASE_STATS
+    if (threadIdx.x < RT_SECTIONS) { s_sec_lanes[threadIdx.x] = 0ull; s_sec_runs[threadIdx.x] = 0ull; s_sec_cycles[threadIdx.x] = 0ull; }
+    __syncthreads();
     unsigned long long ph[5] = {0ull, 0ull, 0ull, 0ull, 0ull}; // wave cycles: record load, hit record, material, write-back, queue
 #define RT_PHASE(k) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ph[k] += now_ - t_ph; t_ph = now_; } while (0)
     unsigned long long t_ph = __builtin_amdgcn_s_memtime();
@@ -51,12 +55,15 @@ __global__ __launch_bounds__(BLOCK, 2) void shade_kernel(DScene S, CamD cam, Pat
                 if (q_next < n) p_next = qin[q_next];
             }
             if (q < n) {
+                RT_SEC_BEGIN(0);
+                RT_SEC_BEGIN(11);
                 PathRec* rec = ps.rec + p;
                 D3 beta = d3p(rec->beta);
                 D3 L = d3p(rec->L);
                 Best b;
                 b.t = rec->hit_t; b.ref = rec->hit_ref; b.ctx = rec->hit_ctx;
                 RT_PHASE(0);
+                RT_SEC_END(11);
                 if (b.ref == RT_REF_NONE) { // camera.rs:258-260
                     L = L + beta * d3p(cam.background);
                 } else {
@@ -65,7 +72,7 @@ __global__ __launch_bounds__(BLOCK, 2) void shade_kernel(DScene S, CamD cam, Pat
                     wr.dx = rec->d[0]; wr.dy = rec->d[1]; wr.dz = rec->d[2];
                     double time = rec->time;
                     HitRec h;
-                    finalize(S, wr, time, b, h, TEXTURES && S.uses_uv != 0u); // only an image texture reads u,v (texture.rs:88-107)
+                    finalize(S, xt, wr, time, b, h, TEXTURES && S.uses_uv != 0u); // only an image texture reads u,v (texture.rs:88-107)
                     if (TEXTURES && ps.uv && (b.ref >> 28) == RT_REF_MEDIUM) { // a medium hit reports the u,v its record held (extend_kernel left them here)
                         const double2 uv = ps.uv[p];
                         h.u = uv.x; h.v = uv.y;
@@ -77,7 +84,9 @@ __global__ __launch_bounds__(BLOCK, 2) void shade_kernel(DScene S, CamD cam, Pat
                     Rng g{seed, 0u, (uint32_t)(j * cam.image_width + i), (uint32_t)(bg.sample0 + (int32_t)s_local), rec->rng_index};
                     D3 ray_dir = d3(wr.dx, wr.dy, wr.dz);
                     D3 nd;
+                    RT_SEC_BEGIN(12);
                     alive = shade_hit<TEXTURES, RR>(S, h, ray_dir, g, beta, L, nd);
+                    RT_SEC_END(12);
                     RT_PHASE(2);
                     if (alive) {
                         if (last_bounce) { // the next ray_color call has depth 0 and returns black (camera.rs:252-254)
@@ -92,6 +101,7 @@ __global__ __launch_bounds__(BLOCK, 2) void shade_kernel(DScene S, CamD cam, Pat
                     }
                 }
                 rec->L[0] = L.x; rec->L[1] = L.y; rec->L[2] = L.z;
+                RT_SEC_END(0);
             }
             RT_PHASE(3);
             const unsigned long long mask = __ballot(alive);
@@ -115,6 +125,12 @@ __global__ __launch_bounds__(BLOCK, 2) void shade_kernel(DScene S, CamD cam, Pat
     }
 #ifdef RT_PHASE_STATS
     if (lane == 0u) for (int k = 0; k < 5; ++k) atomicAdd(&ps.counters[24 + k], ph[k]);
+    __syncthreads();
+    if (threadIdx.x < RT_SECTIONS) { // behind the work slots: lanes, runs, cycles per section
+        atomicAdd(&ps.counters[C_STATS + threadIdx.x], s_sec_lanes[threadIdx.x]);
+        atomicAdd(&ps.counters[C_STATS + RT_SECTIONS + threadIdx.x], s_sec_runs[threadIdx.x]);
+        atomicAdd(&ps.counters[C_STATS + 2 * RT_SECTIONS + threadIdx.x], s_sec_cycles[threadIdx.x]);
+    }
 #endif
 #undef RT_PHASE
 }
@@ -129,6 +145,8 @@ __global__ __launch_bounds__(BLOCK) void tail_kernel(DScene S, CamD cam, PathSta
                                                      int first_bounce, int max_depth) {
     __shared__ uint32_t s_stack[STACK_MAX * BLOCK];
     uint32_t* stk = s_stack + threadIdx.x;
+    __shared__ DXform s_xforms[XF_LDS];
+    const XfTable xt = xf_fill_lds(S, s_xforms);
     const unsigned long long n = ps.counters[C_LIVE_IN];
     const uint32_t* queue = ps.queue[qsel];
     const unsigned long long threads = (unsigned long long)gridDim.x * blockDim.x;
@@ -161,7 +179,7 @@ __global__ __launch_bounds__(BLOCK) void tail_kernel(DScene S, CamD cam, PathSta
                 break;
             }
             HitRec h;
-            finalize(S, r, time, b, h, TEXTURES && S.uses_uv != 0u);
+            finalize(S, xt, r, time, b, h, TEXTURES && S.uses_uv != 0u);
             if (UV && (b.ref >> 28) == RT_REF_MEDIUM) stale_uv(S, w, time, uvt, h.u, h.v);
             D3 ray_dir = d3(r.dx, r.dy, r.dz);
             D3 nd;

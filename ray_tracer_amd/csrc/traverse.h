@@ -51,17 +51,47 @@ RT_DEV void apply_xform(const DXform& x, RayD& r) {
 // Ray of this lane in context `ctx`: the world ray pushed through the chain of
 // transforms from the outermost to `ctx`, one rounding per reference operation.
 // `r` holds the world ray (origin and direction) on entry.
-RT_DEV void world_to_context(const DScene& S, int32_t ctx, RayD& r) {
+// The transform records of a scene, with the first ones copied into LDS by kernels that read them per lane and per hit
+// (shading: a record fetched from memory by a handful of lanes costs the whole wave a memory round trip, and
+// completing the record of a hit inside Translate(RotateY(..)) takes seven of them one after the other; measured
+// on the Cornell box: a quarter of the shading kernel's wave time).  n_lds = 0: no copy, every record from memory.
+constexpr int XF_LDS = 64;
+typedef const __attribute__((address_space(3))) DXform* LdsXforms;
+struct XfTable {
+    const DXform* mem;
+    LdsXforms lds;
+    int32_t n_lds;
+};
+RT_DEV XfTable xf_from_memory(const DScene& S) { return XfTable{S.xforms, nullptr, 0}; }
+RT_DEV DXform xf_get(const XfTable& t, int32_t i) {
+    if (i < t.n_lds) {
+        DXform x;
+        x.kind = t.lds[i].kind; x.parent = t.lds[i].parent; x.child = t.lds[i].child; x.depth = t.lds[i].depth;
+        x.a[0] = t.lds[i].a[0]; x.a[1] = t.lds[i].a[1]; x.a[2] = t.lds[i].a[2];
+        return x;
+    }
+    return t.mem[i];
+}
+// Fills a workgroup's copy (every thread calls it; ends with a barrier).
+RT_DEV XfTable xf_fill_lds(const DScene& S, DXform* table) {
+    const int32_t n = (int32_t)(S.n_xforms < (uint32_t)XF_LDS ? S.n_xforms : (uint32_t)XF_LDS);
+    for (int32_t i = (int32_t)threadIdx.x; i < n; i += (int32_t)blockDim.x) table[i] = S.xforms[i];
+    __syncthreads();
+    return XfTable{S.xforms, (LdsXforms)table, n};
+}
+
+RT_DEV void world_to_context(const XfTable& xt, int32_t ctx, RayD& r) {
     if (ctx != 0) {
-        int depth = S.xforms[ctx - 1].depth;
+        int depth = xf_get(xt, ctx - 1).depth;
         for (int level = 1; level <= depth; ++level) {
             int32_t c = ctx;
-            for (int k = depth; k > level; --k) c = S.xforms[c - 1].parent;
-            apply_xform(S.xforms[c - 1], r);
+            for (int k = depth; k > level; --k) c = xf_get(xt, c - 1).parent;
+            apply_xform(xf_get(xt, c - 1), r);
         }
     }
     set_inverse(r);
 }
+RT_DEV void world_to_context(const DScene& S, int32_t ctx, RayD& r) { world_to_context(xf_from_memory(S), ctx, r); }
 RT_DEV void ray_in_context(const DScene& S, const WorldRay& w, int32_t ctx, RayD& r) {
     r.ox = w.ox[w.i]; r.oy = w.oy[w.i]; r.oz = w.oz[w.i];
     r.dx = w.dx[w.i]; r.dy = w.dy[w.i]; r.dz = w.dz[w.i];
@@ -157,9 +187,18 @@ __shared__ unsigned long long s_step_cycles[8];
 __shared__ uint32_t s_lane_iters[256]; // loop iterations of each lane's current traversal
 #define RT_STEP_BEGIN() const unsigned long long step_t0_ = __builtin_amdgcn_s_memtime()
 #define RT_STEP_END(k) do { if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) atomicAdd(&s_step_cycles[k], (unsigned long long)__builtin_amdgcn_s_memtime() - step_t0_); } while (0)
+// Sections of the shading kernel (stats build only): for every execution of a section by a wave, the lanes that took
+// part, and the wave's cycles from its begin to its end.  A section must end with the lanes it began with.
+constexpr int RT_SECTIONS = 24;
+__shared__ unsigned long long s_sec_lanes[RT_SECTIONS], s_sec_runs[RT_SECTIONS], s_sec_cycles[RT_SECTIONS];
+#define RT_SEC_BEGIN(k) const unsigned long long sec_m_##k = __builtin_amdgcn_ballot_w64(true); const unsigned long long sec_t_##k = __builtin_amdgcn_s_memtime()
+#define RT_SEC_END(k) do { if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(sec_m_##k)) { atomicAdd(&s_sec_lanes[k], (unsigned long long)__popcll(sec_m_##k)); \
+        atomicAdd(&s_sec_runs[k], 1ull); atomicAdd(&s_sec_cycles[k], (unsigned long long)__builtin_amdgcn_s_memtime() - sec_t_##k); } } while (0)
 #else
 #define RT_STEP_BEGIN() do { } while (0)
 #define RT_STEP_END(k) do { } while (0)
+#define RT_SEC_BEGIN(k) do { } while (0)
+#define RT_SEC_END(k) do { } while (0)
 #endif
 
 // Whose surface coordinates the reference's HitRecord would hold.  ConstantMedium::hit writes t, p, normal,
@@ -488,8 +527,11 @@ RT_DEV void set_face_normal(HitRec& h, D3 dir, D3 outward_normal) { // hittable.
 // want_uv = false skips the surface coordinates (sphere: acos + atan2, sphere.rs:47-55; quad and triangle: the fetch of
 // everything but normal and material) for callers that know nothing reads them.
 // `r` holds the world ray on entry (it is taken into the context of the hit here).
-RT_DEV void finalize(const DScene& S, RayD r, double time, const Best& b, HitRec& h, bool want_uv = true) {
-    world_to_context(S, b.ctx, r);
+RT_DEV void finalize(const DScene& S, const XfTable& xt, RayD r, double time, const Best& b, HitRec& h, bool want_uv = true) {
+    RT_SEC_BEGIN(1);
+    world_to_context(xt, b.ctx, r);
+    RT_SEC_END(1);
+    RT_SEC_BEGIN(2);
     const D3 o = d3(r.ox, r.oy, r.oz), d = d3(r.dx, r.dy, r.dz);
     const uint32_t kind = b.ref >> 28, idx = b.ref & 0x0FFFFFFFu;
     h.t = b.t;
@@ -537,10 +579,12 @@ RT_DEV void finalize(const DScene& S, RayD r, double time, const Best& b, HitRec
         h.mat = m.mat;
         h.prim = make_ref(RT_REF_MEDIUM, (uint32_t)m.object);
     }
+    RT_SEC_END(2);
+    RT_SEC_BEGIN(3);
     // Unwind the transform chain innermost first: RotateY rotates p and normal back and keeps
     // front_face (hittable.rs:165-179), Translate adds its offset to p (hittable.rs:86).
     for (int32_t c = b.ctx; c != 0;) {
-        const DXform x = S.xforms[c - 1];
+        const DXform x = xf_get(xt, c - 1);
         if (x.kind == 0) {
             h.p = d3(h.p.x + x.a[0], h.p.y + x.a[1], h.p.z + x.a[2]);
         } else {
@@ -551,6 +595,11 @@ RT_DEV void finalize(const DScene& S, RayD r, double time, const Best& b, HitRec
         }
         c = x.parent;
     }
+    RT_SEC_END(3);
+}
+
+RT_DEV void finalize(const DScene& S, RayD r, double time, const Best& b, HitRec& h, bool want_uv = true) {
+    finalize(S, xf_from_memory(S), r, time, b, h, want_uv);
 }
 
 RT_DEV void finalize(const DScene& S, const WorldRay& w, double time, const Best& b, HitRec& h, bool want_uv = true) {
