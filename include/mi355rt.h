@@ -278,11 +278,16 @@ typedef struct rt_hit_batch {
                                      with its exit (through an edge or a corner) is culled there by the reference (aabb.rs:102) but not
                                      by the conservative test, so a primitive touching that edge can be hit here and not there. */
 #define RT_HIT_COUNTERS        2u /* also accumulate node-visit / primitive-test counters (slower) */
-#define RT_HIT_EXACT_CULL      4u /* with RT_HIT_ORDERED: every box is tested exactly as Aabb::hit does (aabb.rs:82-107, f64, a box
-                                     whose clipped interval is a single point is culled); only the order of a node's two children
-                                     follows the ray (the child on the near side of the node's split axis first).  Slower than the
-                                     conservative 4-wide traversal, which also enters boxes the ray merely touches at an edge or
-                                     corner and can so report a hit the reference never tests (see RT_HIT_ORDERED). */
+#define RT_HIT_EXACT_CULL      4u /* with RT_HIT_ORDERED: a box is entered only if Aabb::hit would enter it (aabb.rs:82-107, f64, a box
+                                     whose clipped interval is a single point is culled), nearest box first.  A world that is one BVH
+                                     over primitives is walked on the 4-wide collapse of the reference's own tree: the f32 slab test
+                                     decides alone where it passes with room to spare (more than its rounding error on both ends),
+                                     and the f64 test of Aabb::hit decides the rest.  Hits the reference never tests because it culls a
+                                     touched box (see RT_HIT_ORDERED) are not reported.  What remains of the visit order: when two
+                                     primitives are hit within rounding of each other (a ray through a shared vertex: t equal to
+                                     about 1e-13 relative), the box of one can start, in floating point, a hair behind the other's hit,
+                                     and which of the two is reported depends on which was reached first; the reported hit is always
+                                     a hit the reference's arithmetic produces for that primitive. */
 
 /* Random numbers drawn inside traversal (constant_medium.rs:90) come from the
  * counter-based stream (seed, stream 2, ray index); see rt_rng_uniform.

@@ -177,6 +177,20 @@ __global__ __launch_bounds__(FAST_BLOCK, (FMT == NODES_PACKED && PREP && !COUNT)
     RayD r;
     Ray32 q;
     float tmin32 = 0.0f, best32 = 0.0f;
+    // EXACT on f32 nodes: a child is taken without the f64 test when the f32 slabs pass with room to spare.  The f32
+    // parameter of a plane lies within 1.75 E of the exact one (E as in Ray32: the deliberate shift, a quarter of it for the
+    // arithmetic, a quarter for the node's outward-rounded f32 planes, a quarter for rounding c -+ E), so with
+    // sure_m = 1.5 * max(cf - cn) >= 2.25 E an interval that is still open after both ends moved inwards by sure_m, and
+    // against tmin rounded up and the closest hit rounded down, is open for Aabb::hit as well.  Infinite 1/d (an
+    // axis-parallel ray: the f32 form drops that axis, Aabb::hit does not) makes sure_m infinite: always the f64 test.
+    float sure_m = 0.0f, tmin32_up = 0.0f, best32_dn = 0.0f;
+    constexpr bool SURE = EXACT && FMT == NODES_F32;
+#define RT_EXACT_SETUP() do { if (SURE) { \
+        const float w_ = fmaxf(fmaxf(q.cf[0] - q.cn[0], q.cf[1] - q.cn[1]), q.cf[2] - q.cn[2]); \
+        const bool fin_ = __builtin_isfinite(q.inv[0]) && __builtin_isfinite(q.inv[1]) && __builtin_isfinite(q.inv[2]) && \
+                          __builtin_isfinite(q.cf[0] - q.cn[0]) && __builtin_isfinite(q.cf[1] - q.cn[1]) && __builtin_isfinite(q.cf[2] - q.cn[2]); \
+        sure_m = (fin_ && !(opt & 8u)) ? 1.5f * w_ : __builtin_inff(); \
+        tmin32_up = f32_round_up(tmin); best32_dn = f32_round_down(best_t); } } while (0)
     // The packed tree is only used with the default lower end of the interval (the host sees to it: its sort keys need
     // tmin >= 0), the same for every ray: it stays in scalar registers.
     const float tmin32_default = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(f32_round_down(tmin_default))));
@@ -252,6 +266,7 @@ __global__ __launch_bounds__(FAST_BLOCK, (FMT == NODES_PACKED && PREP && !COUNT)
                             if (EXACT) set_inverse(r); // Aabb::hit's 1 / d (aabb.rs:88)
                             time = p.time; tmin = p.tmin; best_t = p.tmax;
                             tmin32 = p.tmin32; best32 = p.tmax32;
+                            RT_EXACT_SETUP();
                             best_ref = RT_REF_NONE;
                             pend = RT_REF_NONE;
                             if (SLOT_IN_LDS) s_slot[threadIdx.x] = p.idx; else ray_slot = (slot_t)p.idx;
@@ -273,6 +288,7 @@ __global__ __launch_bounds__(FAST_BLOCK, (FMT == NODES_PACKED && PREP && !COUNT)
                         best_t = (opt & 4u) ? rays.tmax[ri] : D_INF;
                         tmin32 = f32_round_down(tmin);
                         best32 = f32_round_up(best_t);
+                        RT_EXACT_SETUP();
                         best_ref = RT_REF_NONE;
                         pend = RT_REF_NONE;
                         if (SLOT_IN_LDS) s_slot[threadIdx.x] = (uint32_t)i; else ray_slot = (slot_t)i;
@@ -400,10 +416,13 @@ __global__ __launch_bounds__(FAST_BLOCK, (FMT == NODES_PACKED && PREP && !COUNT)
                 float key[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float tn = fmaxf(fmaxf(__builtin_fmaf(nx[j], ax, bnx), __builtin_fmaf(ny[j], ay, bny)), fmaxf(__builtin_fmaf(nz[j], az, bnz), tmin32));
-                    const float tf = fminf(fminf(__builtin_fmaf(fx[j], ax, bfx), __builtin_fmaf(fy[j], ay, bfy)), fminf(__builtin_fmaf(fz[j], az, bfz), best32));
+                    const float tn_ax = fmaxf(fmaxf(__builtin_fmaf(nx[j], ax, bnx), __builtin_fmaf(ny[j], ay, bny)), __builtin_fmaf(nz[j], az, bnz));
+                    const float tf_ax = fminf(fminf(__builtin_fmaf(fx[j], ax, bfx), __builtin_fmaf(fy[j], ay, bfy)), __builtin_fmaf(fz[j], az, bfz));
+                    const float tn = fmaxf(tn_ax, tmin32);
+                    const float tf = fminf(tf_ax, best32);
                     bool hit = (tn <= tf) && (rf[j] != RT_REF_NONE);
-                    if (EXACT && hit) hit = slab_test(S.ebox + ((size_t)((cur & 0x0FFFFFFFu) - S.exact_first) * 4u + (size_t)j) * 6u, r, tmin, best_t);
+                    const bool sure = SURE && fmaxf(tn_ax + sure_m, tmin32_up) < fminf(tf_ax - sure_m, best32_dn);
+                    if (EXACT && hit && !sure) hit = slab_test(S.ebox + ((size_t)((cur & 0x0FFFFFFFu) - S.exact_first) * 4u + (size_t)j) * 6u, r, tmin, best_t);
                     key[j] = hit ? tn : __builtin_inff();
                     if (COUNT) nn += rf[j] != RT_REF_NONE ? 1u : 0u;
                 }
@@ -457,17 +476,17 @@ __global__ __launch_bounds__(FAST_BLOCK, (FMT == NODES_PACKED && PREP && !COUNT)
                         const DTri* tp = S.tris + idx;
                         if (COUNT) ++np;
                         double t, u, v;
-                        if (tri_test(d3p(tp->v0), d3p(tp->v1), d3p(tp->v2), r, tmin, best_t, t, u, v)) { best_t = t; best_ref = pend; best32 = f32_round_up(t); }
+                        if (tri_test(d3p(tp->v0), d3p(tp->v1), d3p(tp->v2), r, tmin, best_t, t, u, v)) { best_t = t; best_ref = pend; best32 = f32_round_up(t); if (SURE) best32_dn = f32_round_down(t); }
                     } else if (PRIM == RT_REF_SPHERE || (PRIM == 0 && kind == RT_REF_SPHERE)) {
                         const DSphere* sph = S.spheres + idx;
                         if (COUNT) ++np;
                         double t;
-                        if (sphere_test(*sph, r, time, tmin, best_t, t)) { best_t = t; best_ref = pend; best32 = f32_round_up(t); }
+                        if (sphere_test(*sph, r, time, tmin, best_t, t)) { best_t = t; best_ref = pend; best32 = f32_round_up(t); if (SURE) best32_dn = f32_round_down(t); }
                     } else { // RT_REF_QUAD
                         const DQuad* qd = S.quads + idx;
                         if (COUNT) ++np;
                         double t, al, be;
-                        if (quad_test(*qd, r, tmin, best_t, t, al, be)) { best_t = t; best_ref = pend; best32 = f32_round_up(t); }
+                        if (quad_test(*qd, r, tmin, best_t, t, al, be)) { best_t = t; best_ref = pend; best32 = f32_round_up(t); if (SURE) best32_dn = f32_round_down(t); }
                     }
                     pend = RT_REF_NONE;
                     if (blocked) { if (postpone_leaves) pend = cur; pop = true; }

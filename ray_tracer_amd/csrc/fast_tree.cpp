@@ -507,6 +507,7 @@ int build_fast_tree(const DTri* tris, FlatScene& f, std::vector<uint8_t>& qdepth
     if (first + wide >= (1ull << 28)) { err = "fast tree: more than 2^28 wide nodes"; return RT_E_TOO_LARGE; }
     // (the kernel addresses the packed arrays by 32-bit byte offsets: they stay below 4 GB; larger meshes keep the 64-byte nodes)
     B.packed = (wide + 4u) * sizeof(PNode) < (1ull << 32) && (leaves + 4u) * sizeof(PTri) < (1ull << 32);
+    f.qnodes.reserve(first + wide + n);             // room for the collapses of the reference's tree behind this one (address space only)
     f.qnodes.resize(first + wide);
     f.cqnodes.resize(first + wide);
     qdepth.resize(first + wide);

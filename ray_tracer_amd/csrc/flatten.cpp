@@ -843,7 +843,7 @@ struct Flattener {
     // ratio capped at 16: close to 1 when siblings are of similar size, large when one huge primitive forces
     // a coarse grid onto its small neighbours all the way up the tree (then the f32 nodes are the better choice).
     double quantise_qnodes() {
-        f.cqnodes.resize(f.qnodes.size()); // (the traversal-only tree has brought its 8-bit nodes along: fast_tree.cpp)
+        f.cqnodes.resize(f.qnodes.size(), CQNode{}); // (the traversal-only tree has brought its 8-bit nodes along: fast_tree.cpp)
         double ratio_sum = fast_ratio_sum;
         uint64_t ratio_n = fast_ratio_n;
         const size_t fast_end = f.fast_tree ? fast_tree_first + fast_tree_count : 0;
@@ -881,7 +881,7 @@ struct Flattener {
             return dx * dy + dy * dz + dz * dx;
         };
         double leaf_area = 0.0;
-        f.pnodes.emplace_back();
+        f.pnodes.push_back(PNode{});
         todo.emplace_back(RT_REF_INDEX(f.fast_root), 0u);
         while (!todo.empty()) {
             const uint32_t q = todo.back().first, me = todo.back().second;
@@ -911,7 +911,7 @@ struct Flattener {
             n.node_base = make_ref(REF_QNODE, node_base);
             n.leaf_base = make_ref(RT_REF_TRI, leaf_base) - (uint32_t)n_inner;
             for (int k = 0; k < n_inner; ++k) {
-                f.pnodes.emplace_back();
+                f.pnodes.push_back(PNode{});
                 todo.emplace_back(RT_REF_INDEX(c.child[order[k]]), node_base + (uint32_t)k);
             }
             for (int k = n_inner; k < n_all; ++k) {

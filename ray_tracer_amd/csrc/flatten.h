@@ -2,6 +2,8 @@
 #ifndef RT_FLATTEN_H
 #define RT_FLATTEN_H
 
+#include <memory>
+#include <new>
 #include <string>
 #include <utility>
 #include <vector>
@@ -13,15 +15,25 @@ struct Box { // aabb.rs:10-14 as xmin xmax ymin ymax zmin zmax
     double b[6];
 };
 
+// A vector whose resize() leaves trivial elements uninitialised: the big node arrays are written exactly once, by the
+// threads that build them, and value-initialising hundreds of megabytes first costs a single-threaded pass over fresh pages.
+template <class T>
+struct DefaultInit : std::allocator<T> {
+    template <class U> struct rebind { using other = DefaultInit<U>; };
+    template <class U> void construct(U* p) noexcept { ::new (static_cast<void*>(p)) U; }
+    template <class U, class... A> void construct(U* p, A&&... a) { ::new (static_cast<void*>(p)) U(std::forward<A>(a)...); }
+};
+template <class T> using RawVec = std::vector<T, DefaultInit<T>>;
+
 struct BuildItem { Box box; uint32_t ref; uint32_t medium; }; // one object of a BVH under construction: bounding_box(), reference, holds-a-medium flag
 
 struct FlatScene {
     std::vector<DNode> nodes;
     std::vector<WNode> wnodes;
-    std::vector<QNode> qnodes;        // 4-wide collapse of the BVH at fast_root (empty otherwise)
-    std::vector<PNode> pnodes;        // packed 48-byte copy of the tree at fast_root (node 0 is the root); empty unless all its leaves are triangles
-    std::vector<PTri> ptris;          // its triangles in leaf order
-    std::vector<CQNode> cqnodes;      // the same nodes with 8-bit boxes (same indices); empty when the grid would be too coarse
+    RawVec<QNode> qnodes;              // 4-wide collapse of the BVH at fast_root (empty otherwise)
+    RawVec<PNode> pnodes;              // packed 48-byte copy of the tree at fast_root (node 0 is the root); empty unless all its leaves are triangles
+    RawVec<PTri> ptris;               // its triangles in leaf order
+    RawVec<CQNode> cqnodes;            // the same nodes with 8-bit boxes (same indices); empty when the grid would be too coarse
     std::vector<DSphere> spheres;
     std::vector<DQuad> quads;
     std::vector<DTri> tris;

@@ -148,8 +148,8 @@ int resolve_scratch(int device) {
     return RT_OK;
 }
 
-template <class T>
-int upload(rt_scene* s, const std::vector<T>& v, const T** out) {
+template <class T, class A>
+int upload(rt_scene* s, const std::vector<T, A>& v, const T** out) {
     *out = nullptr;
     size_t bytes = std::max<size_t>(v.size() * sizeof(T), 256); // never a null pointer in the kernels
     void* p = nullptr;
@@ -203,6 +203,8 @@ Tuning read_tuning() {
     t.prep_vote = env_int("MI355RT_PREP_VOTE", PREP_LEAF_VOTE);
     t.quant = env_int("MI355RT_QUANT", 1) != 0;
     t.exact_fast = env_int("MI355RT_EXACT_FAST", 1) != 0;
+    t.exact_f32 = env_int("MI355RT_EXACT_F32", 1) != 0;
+    t.exact_sure = env_int("MI355RT_EXACT_SURE", 1) != 0;
     t.fast_extend = env_int("MI355RT_FAST_EXTEND", 1) != 0;
     t.shade_textures = env_int("MI355RT_SHADE_TEXTURES", 0) != 0;
     t.reorder = env_int("MI355RT_REORDER", 1);
@@ -302,9 +304,9 @@ int upload_scene(rt_scene* s) {
     // MI355RT_PACKED=0 keeps it on the 64-byte nodes when the packed tree exists
     s->fast_fmt = (!f.cqnodes.empty() && s->tune.quant) ? ((!f.pnodes.empty() && s->tune.packed) ? NODES_PACKED : NODES_8BIT) : NODES_F32;
     s->fast_entry = s->fast_fmt == NODES_PACKED ? make_ref(REF_QNODE, 0u) : f.fast_root;
-    const std::vector<CQNode> no_cqnodes;
-    const std::vector<PNode> no_pnodes;
-    const std::vector<PTri> no_ptris;
+    const RawVec<CQNode> no_cqnodes;
+    const RawVec<PNode> no_pnodes;
+    const RawVec<PTri> no_ptris;
     if ((rc = upload(s, f.qnodes, &d.qnodes))) return rc;
     // (a batch that brings its own tmin array may hold negative ones, which the packed nodes' integer sort keys do not
     // cover: such a batch is traced on the 64-byte nodes, so both copies go to the device)
@@ -436,7 +438,7 @@ int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit
         // the world is one BVH over primitives: dedicated traversal kernel + one pass that completes the records
         int fblocks = (int)std::min<uint64_t>((uint64_t)s->fast_grid_blocks, (waves + (FAST_BLOCK / 64) - 1) / (FAST_BLOCK / 64));
         RayQueue rq{nullptr, nullptr};
-        const uint32_t opt = (rays->time ? 1u : 0u) | (rays->tmin ? 2u : 0u) | (rays->tmax ? 4u : 0u);
+        const uint32_t opt = (rays->time ? 1u : 0u) | (rays->tmin ? 2u : 0u) | (rays->tmax ? 4u : 0u) | (tn.exact_sure ? 0u : 8u);
         // large batches are binned by origin cell and prepared first (reorder.h); the allocation-free entry point
         // (ctx_scratch given) never grows the pass's scratch and so goes without it
         // The pass costs 0.7 ms per 2^24 rays and buys locality and a cheaper refill.  That pays where a ray crosses many
@@ -464,7 +466,7 @@ int launch_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit
         }
         RT_EVENT(ev[1]);
         // the packed nodes order children by keys that need entry distances >= 0, i.e. tmin >= 0: certain only for the default tmin
-        const int fmt = exact_fast ? (s->fast_fmt == NODES_F32 ? NODES_F32 : NODES_8BIT) : ((s->fast_fmt == NODES_PACKED && (opt & 2u)) ? NODES_8BIT : s->fast_fmt);
+        const int fmt = exact_fast ? ((s->fast_fmt == NODES_F32 || tn.exact_f32) ? NODES_F32 : NODES_8BIT) : ((s->fast_fmt == NODES_PACKED && (opt & 2u)) ? NODES_8BIT : s->fast_fmt);
         const uint32_t entry = exact_fast ? s->flat.exact_root : (fmt == s->fast_fmt ? s->fast_entry : s->flat.fast_root);
         // lanes go on past a primitive they have reached where a ray crosses many triangle boxes (bvh_kernel.h);
         // measured on reordered batches: the 2^20-triangle soup (overlap 70) gains 3 %, a closed surface of 1.3 M triangles

@@ -149,6 +149,8 @@ struct Tuning {
     bool quant = true;           // MI355RT_QUANT=0: keep the f32 4-wide nodes
     int postpone = -1;           // MI355RT_POSTPONE=0/1: overrides the choice made from the tree (postponed primitive tests)
     bool exact_fast = true;      // MI355RT_EXACT_FAST=0: RT_HIT_EXACT_CULL keeps the general kernel on the binary nodes
+    bool exact_sure = true;  // MI355RT_EXACT_SURE=0: the f64 test for every accepted child on the f32 nodes as well (the results must not change)
+    bool exact_f32 = true;   // ... on the f32 nodes, where a child that passes with room to spare needs no f64 test (0: 8-bit nodes, f64 test for every accepted child)
     bool packed = true;          // MI355RT_PACKED=0: keep the 64-byte 8-bit nodes where the 48-byte packed tree exists
     bool fast_extend = true;     // MI355RT_FAST_EXTEND=0: the renderer keeps the general traversal
     bool shade_textures = false; // MI355RT_SHADE_TEXTURES=1: always the full shading kernel

@@ -527,6 +527,13 @@ def test_rays_tangent_to_boxes():
     cull = gpu.closest_hit(o, d, flags=F.RT_HIT_ORDERED | F.RT_HIT_EXACT_CULL)
     assert np.array_equal(cull["t"], want["t"])
     assert np.mean(cull["prim"] != want["prim"]) < 0.05
+    # ... and on rays a hair off the edges, on either side of what f32 slabs can tell apart: the exact-cull traversal takes a
+    # child on the strength of the f32 test alone only when that test passes with room to spare
+    for eps in (1e-13, 1e-10, 1e-8, 1e-7, 1e-6, 1e-5):
+        for sign in (1.0, -1.0):
+            oe = o + sign * eps * np.array([0.37, -0.21, 0.13])
+            ce, we = gpu.closest_hit(oe, d, flags=F.RT_HIT_ORDERED | F.RT_HIT_EXACT_CULL), cpu.closest_hit(oe, d)
+            assert np.array_equal(ce["t"], we["t"]), (eps, sign)
     o2 = o + 1e-3 * np.array([0.37, -0.21, 0.13])
     a, b = gpu.closest_hit(o2, d, flags=F.RT_HIT_ORDERED), cpu.closest_hit(o2, d)
     assert np.array_equal(a["t"], b["t"])
@@ -569,6 +576,7 @@ def test_rays_at_shared_edges_and_vertices_from_far_away(monkeypatch):
     tris = scenes.icosphere_mesh(subdiv=4)
     desc = rt.SceneDesc.from_world(rt.Mesh(tris, m))
     scan = O.OracleScene(rt.SceneDesc.from_world(rt.ObjModel(tris, m)))
+    bvh = O.OracleScene(desc)
     g = np.random.default_rng(77)
     verts = tris.reshape(-1, 3)
     mids = 0.5 * (tris[:, 0] + tris[:, 1])
@@ -590,7 +598,57 @@ def test_rays_at_shared_edges_and_vertices_from_far_away(monkeypatch):
             same = a["prim"] == b["prim"]  # several triangles meet at every target: any of those tied at the closest t may be reported
             for f in ("u", "v", "front_face", "mat", "nx", "ny", "nz"):
                 assert np.array_equal(a[f][same], b[f][same]), f
+            # RT_HIT_EXACT_CULL on the same rays: the reference's own answer (its BVH culls boxes touched at a point,
+            # so some of the hits above are missed there too), also where f32 slabs cannot tell touching from crossing
+            c = gpu.closest_hit(o, d, flags=F.RT_HIT_ORDERED | F.RT_HIT_EXACT_CULL)
+            w = bvh.closest_hit(o, d, nthreads=8)
+            # every ray here goes through a point where five or six triangles meet, so their hits lie within rounding of each
+            # other and a box can begin, in floating point, just behind a neighbour's hit: which of them is kept then depends
+            # on the visit order.  No hit appears or disappears, and t agrees to rounding; on nearly all rays exactly.
+            assert np.array_equal(c["prim"] == F.RT_REF_NONE, w["prim"] == F.RT_REF_NONE)
+            hit = w["prim"] != F.RT_REF_NONE
+            assert np.all(np.abs(c["t"][hit] - w["t"][hit]) <= 1e-12 * np.abs(w["t"][hit]))
+            assert np.mean(c["t"][hit] != w["t"][hit]) < 0.02
         gpu.close()
+    # the f32 short cut of the exact-cull traversal decides nothing differently: every output is the same with it off
+    o, d = targets - dirs * 1e3, dirs
+    res = []
+    for sure in ("1", "0"):
+        monkeypatch.setenv("MI355RT_EXACT_SURE", sure)
+        gpu = rt.Scene(desc)
+        res.append(gpu.closest_hit(o, d, flags=F.RT_HIT_ORDERED | F.RT_HIT_EXACT_CULL))
+        gpu.close()
+    for f in res[0]:
+        assert np.array_equal(res[0][f].view(np.uint8), res[1][f].view(np.uint8)), f
+
+
+def test_exact_cull_on_f32_nodes_with_and_without_the_short_cut(monkeypatch):
+    """RT_HIT_ORDERED | RT_HIT_EXACT_CULL on a mesh walks the collapse of the reference's tree on f32 nodes and asks
+    Aabb::hit's f64 arithmetic (aabb.rs:82-107) only where the f32 slabs leave room for doubt.  On a soup of 2^17
+    triangles: equal to the oracle on a sample, and byte for byte the same outputs over 2^21 rays whether the short cut
+    is taken or every accepted child is confirmed in f64 (MI355RT_EXACT_SURE=0), traced as they come and through the
+    binning pass, and on axis-parallel rays, whose infinite 1/d the f32 form cannot bound."""
+    desc = rt.SceneDesc.from_world(scenes.triangle_soup_scene(1 << 17, seed=2))
+    o, d, _ = scenes.incoherent_rays(1 << 21, [0, 1, 0, 1, 0, 1], seed=5)
+    d[::7, 0] = 0.0          # axis-parallel in x
+    d[::11, 1:] = 0.0        # along the x axis
+    flags = F.RT_HIT_ORDERED | F.RT_HIT_EXACT_CULL
+    res = {}
+    for sure in ("1", "0"):
+        monkeypatch.setenv("MI355RT_EXACT_SURE", sure)
+        gpu = rt.Scene(desc)
+        res[sure, "pass"] = gpu.closest_hit(o, d, flags=flags)             # 2^21 >= the binning pass's threshold
+        res[sure, "plain"] = gpu.closest_hit(o[:100000], d[:100000], flags=flags)
+        gpu.close()
+    for leg in ("pass", "plain"):
+        for f in res["1", leg]:
+            assert np.array_equal(res["1", leg][f].view(np.uint8), res["0", leg][f].view(np.uint8)), (leg, f)
+    want = O.OracleScene(desc).closest_hit(o[:30000], d[:30000], nthreads=8)
+    assert (want["prim"] != F.RT_REF_NONE).sum() > 5000
+    for leg, n in (("pass", 30000), ("plain", 30000)):
+        got = res["1", leg]
+        assert np.array_equal(got["t"][:n].view(np.uint64), want["t"].view(np.uint64)), leg
+        assert np.mean(got["prim"][:n] != want["prim"]) < 0.01
 
 
 def test_one_scene_from_several_threads():
