@@ -32,6 +32,7 @@ extern "C" {
 #define RT_E_HIP         -2   /* HIP runtime error (no device, out of memory, launch failure) */
 #define RT_E_UNSUPPORTED -3   /* valid in the reference but outside what the kernels implement */
 #define RT_E_TOO_LARGE   -4   /* exceeds a stated fixed limit */
+#define RT_E_BUSY        -5   /* a shared resource is still in use by work enqueued elsewhere (rt_closest_hit_device_noalloc) */
 
 typedef struct rt_scene rt_scene; /* opaque: flattened scene + device buffers */
 
@@ -321,7 +322,10 @@ int rt_scene_reserve(rt_scene* scene, uint64_t max_rays, uint64_t max_paths);
  *   - n <= RT_NOALLOC_MAX_RAYS, else RT_E_TOO_LARGE;
  *   - calls no hipMalloc / hipFree; the array's address is resolved per device by rt_scene_create;
  *   - every call on one GPU shares that GPU's array: calls that overlap on one GPU (two streams, two
- *     scenes, two threads) race on it and must be serialised by the caller. */
+ *     scenes, two threads) would race on it and must be serialised by the caller.  The library checks what it
+ *     can see: a call on another stream than the previous one, while that one's work has not finished, returns
+ *     RT_E_BUSY and enqueues nothing (calls on one stream follow each other and are always accepted; nothing is
+ *     checked, or recorded, on a stream that is being captured into a graph). */
 #define RT_NOALLOC_MAX_RAYS (1ull << 24)
 int rt_closest_hit_device_noalloc(rt_scene* scene, const rt_ray_batch* rays, uint64_t n,
                                   rt_hit_batch* hits, uint64_t seed, uint32_t flags,

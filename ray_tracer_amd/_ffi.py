@@ -18,6 +18,7 @@ RT_E_INVALID = -1
 RT_E_HIP = -2
 RT_E_UNSUPPORTED = -3
 RT_E_TOO_LARGE = -4
+RT_E_BUSY = -5
 
 RT_SCENE_HOST_ONLY = 1
 

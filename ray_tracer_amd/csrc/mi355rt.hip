@@ -137,6 +137,10 @@ struct SceneCall {
 constexpr int NOALLOC_MAX_DEVICES = 64;
 int32_t* g_scratch_ptr[NOALLOC_MAX_DEVICES] = {};
 std::mutex g_scratch_mutex;
+// Who used a device's array last: the allocation-free entry point refuses a call from another stream while that work
+// is still running (the array would be overwritten under it).  The event is created with the address, at scene creation.
+struct ScratchUse { std::mutex m; hipEvent_t done = nullptr; hipStream_t stream = nullptr; bool pending = false; };
+ScratchUse g_scratch_use[NOALLOC_MAX_DEVICES];
 
 int resolve_scratch(int device) {
     if (device < 0 || device >= NOALLOC_MAX_DEVICES) return RT_OK; // such a device simply has no allocation-free entry point
@@ -144,6 +148,7 @@ int resolve_scratch(int device) {
     if (g_scratch_ptr[device]) return RT_OK;
     int32_t* ptr = nullptr;
     HIP_TRY(hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(scratch)));
+    HIP_TRY(hipEventCreateWithFlags(&g_scratch_use[device].done, hipEventDisableTiming));
     g_scratch_ptr[device] = ptr;
     return RT_OK;
 }
@@ -862,7 +867,25 @@ int rt_closest_hit_device_noalloc(rt_scene* s, const rt_ray_batch* rays, uint64_
     int32_t* const ptr = (s->device >= 0 && s->device < NOALLOC_MAX_DEVICES) ? g_scratch_ptr[s->device] : nullptr;
     if (!ptr) return set_err(RT_E_HIP, "rt_closest_hit_device_noalloc: the scratch array of this device was not resolved at scene creation");
     SceneCall call(s, static_cast<hipStream_t>(hip_stream), false); // host-side state only: see SceneCall
-    return launch_closest_hit(s, rays, n, hits, seed, flags, call.st, ptr);
+    ScratchUse& use = g_scratch_use[s->device];
+    std::lock_guard<std::mutex> guard(use.m);
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    HIP_TRY(hipStreamIsCapturing(call.st, &capturing));
+    const bool watched = capturing == hipStreamCaptureStatusNone; // (an event recorded during capture is a graph node, not a time)
+    if (watched && use.pending && use.stream != call.st) {
+        const hipError_t q = hipEventQuery(use.done);
+        if (q == hipErrorNotReady)
+            return set_err(RT_E_BUSY, "rt_closest_hit_device_noalloc: the previous allocation-free call on this GPU, on another stream, has not finished; its scratch would be overwritten");
+        if (q != hipSuccess) return set_err(RT_E_HIP, std::string("hipEventQuery: ") + hipGetErrorString(q));
+        use.pending = false;
+    }
+    rc = launch_closest_hit(s, rays, n, hits, seed, flags, call.st, ptr);
+    if (watched && n) {
+        HIP_TRY(hipEventRecord(use.done, call.st));
+        use.stream = call.st;
+        use.pending = true;
+    }
+    return rc;
 }
 
 int rt_closest_hit(rt_scene* s, const rt_ray_batch* rays, uint64_t n, rt_hit_batch* hits, uint64_t seed, uint32_t flags) {

@@ -1,7 +1,7 @@
 """BvhNode::from_objects (bvh.rs:20-77) built on the device (bvh_build.hip: level-synchronous, two stable radix sorts
-per level) against the host recursion of the flattener, which tests/test_host_flatten.py holds one-to-one against the
-oracle's tree: the node array (f64 bounds, child references, flags) and the 4-wide nodes derived from it must be
-identical byte for byte."""
+per level) against the oracle's own tree (its pre-order dump: bounds, children, which primitive sits where) and against
+the host recursion of the flattener: the node array (f64 bounds, child references, flags) and the 4-wide nodes derived
+from it must be identical byte for byte."""
 import numpy as np
 import pytest
 
@@ -59,3 +59,32 @@ def test_device_built_bvh_of_the_benchmark_mesh(monkeypatch):
     a, b = dev.nodes(), host.nodes()
     assert len(a) == (1 << 20) - 1 and a.tobytes() == b.tobytes()
     assert dev.wide_nodes().tobytes() == host.wide_nodes().tobytes()
+
+
+def test_device_built_bvh_equals_the_oracle_tree(monkeypatch):
+    """The device build against BvhNode::from_objects as the oracle restates it, node for node in pre-order: split axis
+    by longest extent (bvh.rs:27-33), stable order among equal keys (bvh.rs:44-46), spans of one, two and more objects."""
+    from test_host_flatten import _compare_bvh
+    monkeypatch.setenv("MI355RT_DEVICE_BVH_MIN", "1")
+    m = rt.Lambertian(rt.Color(.5, .5, .5))
+    rng = np.random.default_rng(11)
+    cases = []
+    for n in (1, 2, 3, 5, 8, 33, 100, 1000):
+        cases.append(rt.SceneDesc.from_world(rt.SphereSet(rng.uniform(-5, 5, (n, 3)), rng.uniform(0.05, 0.4, n), m, bvh=True)))
+    g = np.stack(np.meshgrid(np.arange(6.0), np.arange(5.0), np.arange(4.0), indexing="ij"), -1).reshape(-1, 3)
+    cases.append(rt.SceneDesc.from_world(rt.SphereSet(g, np.full(len(g), 0.25), m, bvh=True)))                       # ties on every axis
+    cases.append(rt.SceneDesc.from_world(rt.Mesh(scenes.icosphere_mesh(subdiv=4), m)))
+    cases.append(rt.SceneDesc.from_world(scenes.triangle_soup_scene(1 << 15, seed=2)))
+    for desc in cases:
+        dev = rt.Scene(desc)
+        obj = desc.world
+        o = desc.arrays["objects"][obj]
+        if o["kind"] == F.RT_OBJ_LIST and o["b"] == 1 and o["child_kind"] == F.RT_CHILD_OBJECTS:
+            obj = int(desc.arrays["children"][o["a"]])
+        assert _compare_bvh(desc, obj, scene=dev) >= 1
+        dev.close()
+    world, lights, cam = scenes.book1_final(seed=0, moving=True)
+    desc = rt.SceneDesc.from_world(world, lights)
+    dev = rt.Scene(desc)
+    assert _compare_bvh(desc, int(desc.arrays["children"][desc.arrays["objects"][desc.world]["a"]]), scene=dev) >= 255
+    dev.close()

@@ -275,6 +275,36 @@ def test_render_device_entry_point_with_rank_units_on_a_stream():
     assert np.allclose(acc.cpu().numpy(), full, rtol=1e-12, atol=1e-12, equal_nan=True)
 
 
+def test_frame_job_exchanges_run_on_the_device():
+    """render_frame_job as bench.py --gpus N runs it, here with a process group of one rank on RCCL: every pairing of
+    partition and frame-end exchange (strata + reduce, strata + reduce_scatter by band owner + gather, tiles + gather,
+    tiles + reduce) goes through the collective on the device accumulator and must return the unsplit frame."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from ray_tracer_amd import parallel
+    world, lights, cam = scenes.cornell_box(image_width=48, samples_per_pixel=16, max_depth=10)
+    gpu = rt.Scene(rt.SceneDesc.from_world(world, lights))
+    c = cam.to_struct()
+    d = O.camera_initialize(c)
+    full = gpu.render(c, seed=11)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        unit = lambda w, a: gpu.render_device(c, a, seed=11, work=w, stream=torch.cuda.current_stream().cuda_stream)
+        for mode, collective in (("strata", "reduce"), ("strata", "reduce_scatter"), ("tiles", "gather"), ("tiles", "reduce")):
+            acc = torch.zeros((d.image_height, c.image_width, 3), dtype=torch.float64, device="cuda")
+            acc, tm = parallel.render_frame_job(unit, acc, c.image_width, d.image_height, d.sqrt_spp * d.sqrt_spp, dist=dist, mode=mode,
+                                                sync=torch.cuda.synchronize, collective=collective)
+            assert tm["collective"] == collective and tm["reduce_s"] > 0.0
+            assert tm["paths"] == c.image_width * d.image_height * d.sqrt_spp * d.sqrt_spp
+            assert np.allclose(acc.cpu().numpy(), full, rtol=1e-12, atol=1e-12, equal_nan=True), (mode, collective)
+    finally:
+        dist.destroy_process_group()
+
+
 def test_shading_variants_agree_bit_for_bit(monkeypatch):
     """Scenes whose textures are all solid colours are shaded by a kernel compiled without the texture code
     (fewer registers, one more wave per SIMD).  MI355RT_SHADE_TEXTURES=1 forces the full kernel: two

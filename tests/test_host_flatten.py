@@ -37,9 +37,10 @@ def test_rng_matches_oracle_stream():
         assert F.lib.rt_rng_uniform(0x1234567890ABCDEF, 1, 7, 9, idx) == O.olib.oracle_rng_uniform(0x1234567890ABCDEF, 1, 7, 9, idx)
 
 
-def _compare_bvh(desc, obj_id):
-    """Product pre-order node array vs oracle pre-order dump for the BVH object `obj_id`."""
-    host = rt.Scene(desc, host_only=True)
+def _compare_bvh(desc, obj_id, scene=None):
+    """Product pre-order node array vs oracle pre-order dump for the BVH object `obj_id` (`scene`: a scene made from
+    `desc` some other way than by the host recursion)."""
+    host = scene if scene is not None else rt.Scene(desc, host_only=True)
     orc = O.OracleScene(desc)
     want = orc.bvh_dump(obj_id)
     nodes = host.nodes()

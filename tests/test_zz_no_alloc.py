@@ -92,3 +92,37 @@ def test_noalloc_entry_point_rejects_oversized_batches():
     rc = F.lib.rt_closest_hit_device_noalloc(gpu.handle, C.byref(rb), F.RT_NOALLOC_MAX_RAYS + 1, C.byref(hb), 0, 0, None)
     assert rc == F.RT_E_TOO_LARGE and b"2^24" in F.lib.rt_last_error()
     gpu.close()
+
+
+def test_overlapping_allocation_free_calls_are_refused():
+    """All allocation-free calls on one GPU share one scratch array.  A call on another stream while the previous one's
+    work is still running would overwrite it: the library returns RT_E_BUSY and enqueues nothing; once that work has
+    finished, and always on the same stream, calls are accepted, from any scene."""
+    import torch
+    dev = torch.device("cuda", 0)
+    world, lights, _ = scenes.cornell_box()
+    gpu = rt.Scene(rt.SceneDesc.from_world(world, lights))
+    world2, lights2, _ = scenes.book2_final(seed=0)
+    other = rt.Scene(rt.SceneDesc.from_world(world2, lights2))
+    n = 1 << 22
+    o, d, tm = scenes.incoherent_rays(n, [1, 554, 1, 554, 1, 554], seed=43)
+    rays = _device_rays(torch, dev, o, d, tm)
+    hits = {f: torch.empty((n,), dtype=getattr(torch, _TORCH_DT.get(f, "float64")), device=dev) for f in HIT_FIELDS}
+    hits2 = {f: torch.empty((1000,), dtype=getattr(torch, _TORCH_DT.get(f, "float64")), device=dev) for f in HIT_FIELDS}
+    small = {k: v[:1000].contiguous() for k, v in rays.items()}
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for scene in (gpu, other):  # (a kernel's first launch in a process loads its code and blocks the host for that long)
+        scene.closest_hit_device(small, hits2, 1000, seed=5, flags=0, stream=s1.cuda_stream, noalloc=True)
+    torch.cuda.synchronize()
+    gpu.closest_hit_device(rays, hits, n, seed=5, flags=0, stream=s1.cuda_stream, noalloc=True)          # about half a millisecond of work
+    with pytest.raises(rt.RtError) as err:
+        other.closest_hit_device(small, hits2, 1000, seed=5, flags=0, stream=s2.cuda_stream, noalloc=True)
+    assert err.value.code == F.RT_E_BUSY
+    gpu.closest_hit_device(small, hits2, 1000, seed=5, flags=0, stream=s1.cuda_stream, noalloc=True)     # same stream: in order
+    torch.cuda.synchronize()
+    want = {f: hits2[f].cpu().numpy().copy() for f in HIT_FIELDS}
+    gpu.closest_hit_device(small, hits2, 1000, seed=5, flags=0, stream=s2.cuda_stream, noalloc=True)     # the device is idle: accepted
+    torch.cuda.synchronize()
+    _same({f: hits2[f].cpu().numpy() for f in HIT_FIELDS}, want)
+    gpu.close()
+    other.close()
