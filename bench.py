@@ -147,7 +147,7 @@ def main() -> None:
         "metric": "Mrays/s closest-hit", "value": mrays, "unit": "Mrays/s", "n_gpus": world_size, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"closest-hit, {args.triangles}-triangle soup Mesh (BVH, reference split order), "
+        "config": {"workload": f"closest-hit, {args.triangles}-triangle soup Mesh (bvh.rs tree for the reference's visit order; RT_HIT_ORDERED walks a traversal-only tree over the same triangles), "
                                f"{n} incoherent f64 rays per GPU per step", "traversal": args.mode,
                    "bvh_nodes": int(info.n_nodes), "scene_bytes": int(info.device_bytes), "hit_fraction": hit_frac,
                    "scene_build_s": build_s, "device_ms_per_step": dev_ms},

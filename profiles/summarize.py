@@ -2,7 +2,7 @@
 """Turns the rocprofv3 outputs of one round (kernel trace + counter passes, merged back under
 gpurun_out/) into the tracked summaries under profiles/:  <tag>_kernel_stats.csv,
 <tag>_counters.csv, <tag>_summary.md and traffic.json (HBM-side bytes per launch of the dominant
-kernel, read by bench.py).  Usage: python profiles/summarize.py r1 <kernel-name-substring>"""
+kernel, read by bench.py).  Usage: python profiles/summarize.py r1 <kernel-name> [<regex for the instantiation>]"""
 import csv
 import glob
 import json
@@ -10,20 +10,28 @@ import os
 import shutil
 import sys
 
+import re
+
 tag, kernel = sys.argv[1], sys.argv[2]
+# which instantiation: by default the one bench.py's headline leg launches (no counters, not the exact-cull variant, whose
+# template arguments end in "true"); a third argument overrides the pattern
+pattern = re.compile(sys.argv[3] if len(sys.argv) > 3 else re.escape(kernel) + r"<\d+, ?false, ?\d+, ?\d+, ?(true|false)(, ?false)?>")
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out")
 dst = os.path.join(root, "profiles")
 
 newest = lambda files: sorted(files, key=os.path.getmtime)[-1:]  # gpurun merges results into what earlier calls left: only the last run of a pass counts
 stats = newest(glob.glob(os.path.join(src, f"{tag}_trace", "*", "*_kernel_stats.csv")))
-avg_ns = None
+avg_ns, chosen = None, None
 if stats:
     shutil.copy(stats[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
+    best_total = -1.0
     for row in csv.DictReader(open(stats[0])):
-        if kernel in row["Name"] and "false" in row["Name"]:
-            avg_ns = float(row["AverageNs"])
+        if pattern.search(row["Name"]) and float(row["TotalDurationNs"]) > best_total:  # several instantiations may match: the one the time went to
+            best_total, avg_ns, chosen = float(row["TotalDurationNs"]), float(row["AverageNs"]), row["Name"]
 
+m_inst = re.search(re.escape(kernel) + r"<[^>]*>", chosen) if chosen else None
+chosen_inst = m_inst.group(0) if m_inst else None  # e.g. "bvh4_closest_hit_kernel<3, false, 2, 1, true, false>"
 vals = {}
 for d in (f"{tag}_pmc", f"{tag}_pmc_mem"):
     passes = {}
@@ -31,7 +39,7 @@ for d in (f"{tag}_pmc", f"{tag}_pmc_mem"):
         passes.setdefault(os.path.dirname(f), []).append(f)
     for f in [g for files in passes.values() for g in newest(files)]:
         for row in csv.DictReader(open(f)):
-            if kernel in row["Kernel_Name"] and "false" in row["Kernel_Name"]:
+            if (chosen_inst in row["Kernel_Name"]) if chosen_inst else pattern.search(row["Kernel_Name"]):
                 vals.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
 mean = {k: sum(v) / len(v) for k, v in vals.items()}
 with open(os.path.join(dst, f"{tag}_counters.csv"), "w") as fh:
