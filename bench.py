@@ -216,7 +216,7 @@ CUS, LANES = 256, 64
 
 
 def _roofline(args, n, dev_ms, box_tests, prim_tests, cpu, o, d, tm, np, shader_khz):
-    """Two roofs for the dominant kernel; `bound` names the one that binds and `frac` is that roof's fraction.
+    """Two roofs for the dominant kernel; `bound` names the one that binds.
 
     HBM: algorithmic bytes per ray = 64 per node visit + 72 per triangle test + 72 (ray in) + 48 (hit out), with the
     visits THIS kernel made (a visit of a 4-wide node = 4 box tests), times the rays of a launch, over the kernel's
@@ -228,8 +228,10 @@ def _roofline(args, n, dev_ms, box_tests, prim_tests, cpu, o, d, tm, np, shader_
     256 CUs x 64 lanes x the shader clock measured during a launch of this kernel.
     The same two formulas on the REFERENCE-ORDER counts of the oracle (left-then-right traversal of the same tree) are
     reported as `ref_order`: they say how much work the ordered traversal avoids, not how fast the kernel is.
-    Which roof binds: the vector-ALU fraction against the fraction of the HBM peak the kernel really pulls
-    (`traffic_frac`; when no profile of this build exists, `frac_requested`, an upper bound of it)."""
+    Which roof binds: with the counter passes of this build at hand, the share of cycles the vector ALUs are issuing
+    (`valu.busy_frac`: idle lanes of an instruction still take the slot) against the share of the HBM peak that really
+    crosses the fabric (`traffic_frac`); without them, `valu.frac` against `frac_requested`.  `achieved`, `peak`, `unit`
+    and `frac` at the top level are the HBM figures on the bytes of the kernel's own visits in either case."""
     kernel_ms = dev_ms["traversal_ms"]
     ordered = args.mode == "ordered"
     node_visits = box_tests / 4.0 if ordered else box_tests
@@ -264,10 +266,19 @@ def _roofline(args, n, dev_ms, box_tests, prim_tests, cpu, o, d, tm, np, shader_
         for k in ("l2_hit_rate", "valu_busy_frac", "valu_lane_utilisation", "wave_wait_frac", "profile"):
             if k in prof:
                 extra[k] = prof[k]
-    hbm_binding = hbm.get("traffic_frac", hbm.get("frac_requested", hbm["frac"]))
-    bound = "valu" if valu["frac"] >= hbm_binding else "hbm"
-    top = valu if bound == "valu" else hbm
-    r = {"bound": bound, "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"], "frac": top["frac"], "traffic": traffic,
+    if "valu_busy_frac" in extra and "traffic_frac" in hbm:
+        # counters of this build: the share of cycles the vector ALUs issue (whatever the lanes do) against the share of
+        # the HBM peak that crosses the fabric
+        valu["busy_frac"], valu["lane_utilisation"] = extra["valu_busy_frac"], extra.get("valu_lane_utilisation")
+        bound = "valu" if valu["busy_frac"] >= hbm["traffic_frac"] else "hbm"
+        basis = (f"counters of this build: vector ALU busy {valu['busy_frac']:.2f} of the cycles at lane utilisation "
+                 f"{valu['lane_utilisation'] or 0:.2f}; fabric traffic {hbm['traffic_frac']:.2f} of the HBM peak")
+    else:
+        hbm_binding = hbm.get("frac_requested", hbm["frac"])
+        bound = "valu" if valu["frac"] >= hbm_binding else "hbm"
+        basis = "formulas only (no counter profile of this build under profiles/): valu.frac against hbm.frac_requested"
+    # achieved / peak / unit / frac stay on the bytes of the kernel's own visits whichever roof binds; the vector-ALU roof is `valu`
+    r = {"bound": bound, "bound_basis": basis, "achieved": hbm["achieved"], "peak": hbm["peak"], "unit": hbm["unit"], "frac": hbm["frac"], "traffic": traffic,
          "kernel": "bvh4_closest_hit_kernel" if ordered else "closest_hit_kernel", "kernel_ms": kernel_ms,
          "node_visits_per_ray": node_visits, "box_tests_per_ray": box_tests, "prim_tests_per_ray": prim_tests,
          "hbm": hbm, "valu": valu,

@@ -92,10 +92,15 @@ if mean:
     ]
 if bench:
     r = bench.get("roofline", {})
+    ro, valu, hbm = r.get("ref_order", {}), r.get("valu", {}), r.get("hbm", {})
     lines += ["", f"bench.py line of the same build: {bench.get('value', 0):.1f} Mrays/s, {bench.get('ms_per_step', 0):.2f} ms/step, "
-                  f"device ms per step {bench.get('config', {}).get('device_ms_per_step')}, "
-                  f"roofline.achieved {r.get('achieved', 0):.0f} GB/s = {r.get('frac', 0):.3f} of peak (bytes of the kernel's own visits), "
-                  f"reference-order equivalent {r.get('ref_order_equivalent_gbs', 0):.0f} GB/s (visit reduction {r.get('visit_reduction', 0):.2f}x), cpu_baseline "
+                  f"device ms per step {bench.get('config', {}).get('device_ms_per_step')}; "
+                  f"{r.get('node_visits_per_ray', 0):.1f} node visits, {r.get('box_tests_per_ray', 0):.0f} box tests and {r.get('prim_tests_per_ray', 0):.2f} primitive tests per ray; "
+                  f"bound: {r.get('bound')}; HBM roof on the bytes of the kernel's own visits {hbm.get('achieved', 0):.0f} GB/s = {hbm.get('frac', 0):.3f} of peak "
+                  f"(on the bytes its formats request {hbm.get('frac_requested', 0):.3f}, on the measured fabric traffic {hbm.get('traffic_frac') or 0:.3f}); "
+                  f"vector-ALU roof {valu.get('achieved', 0):.0f} G lane-instructions/s = {valu.get('frac', 0):.3f} of {valu.get('peak', 0):.0f} at {valu.get('clock_ghz', 0):.2f} GHz; "
+                  f"the same formulas on the reference-order counts: HBM {ro.get('hbm_frac', 0):.2f}, vector ALU {ro.get('valu_frac', 0):.2f} of peak "
+                  f"(visit reduction {ro.get('visit_reduction', 0):.1f}x); cpu_baseline "
                   f"{bench.get('cpu_baseline', {}).get('value', 0):.3f} Mrays/s on {bench.get('cpu_baseline', {}).get('cores', 0)} threads."]
 open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(l for l in lines if l is not None) + "\n")
 print(open(os.path.join(dst, f"{tag}_summary.md")).read())
