@@ -502,6 +502,7 @@ int build_fast_tree(const DTri* tris, FlatScene& f, std::vector<uint8_t>& qdepth
     refs.reset();
     const auto t_2 = std::chrono::steady_clock::now();
     out.stack_need = B.count(broot);
+    const auto t_2a = std::chrono::steady_clock::now();
     const uint64_t wide = B.pool[broot].wide, leaves = B.pool[broot].leaves;
     const size_t first = f.qnodes.size();
     if (first + wide >= (1ull << 28)) { err = "fast tree: more than 2^28 wide nodes"; return RT_E_TOO_LARGE; }
@@ -516,7 +517,9 @@ int build_fast_tree(const DTri* tris, FlatScene& f, std::vector<uint8_t>& qdepth
     B.qn = f.qnodes.data() + first; B.cq = f.cqnodes.data() + first; B.qd = qdepth.data() + first;
     B.pn = f.pnodes.data(); B.pt = f.ptris.data();
     B.q_first = (uint32_t)first;
+    const auto t_2b = std::chrono::steady_clock::now();
     B.emit(broot, 0u, 1u, 0u, 0);
+    const auto t_2c = std::chrono::steady_clock::now();
     out.root = (uint32_t)first;
     out.wide_nodes = wide;
     out.references = leaves;
@@ -538,6 +541,8 @@ int build_fast_tree(const DTri* tris, FlatScene& f, std::vector<uint8_t>& qdepth
         std::fprintf(stderr, "[mi355rt] traversal-only tree: %llu triangles, %llu references, %llu wide nodes; set-up %.3f s, binary tree %.3f s, records %.3f s (%d tasks)\n",
                      (unsigned long long)n, (unsigned long long)leaves, (unsigned long long)wide, std::chrono::duration<double>(t_1 - t_0).count(),
                      std::chrono::duration<double>(t_2 - t_1).count(), std::chrono::duration<double>(t_3 - t_2).count(), B.max_tasks);
+        std::fprintf(stderr, "[mi355rt]   records: count %.3f s, arrays %.3f s, emit %.3f s, measures %.3f s\n", std::chrono::duration<double>(t_2a - t_2).count(),
+                     std::chrono::duration<double>(t_2b - t_2a).count(), std::chrono::duration<double>(t_2c - t_2b).count(), std::chrono::duration<double>(t_3 - t_2c).count());
     }
     return RT_OK;
 }

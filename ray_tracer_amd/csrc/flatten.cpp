@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <future>
+#include <thread>
 #include <limits>
 #include <map>
 #include <numeric>
@@ -847,16 +848,28 @@ struct Flattener {
         double ratio_sum = fast_ratio_sum;
         uint64_t ratio_n = fast_ratio_n;
         const size_t fast_end = f.fast_tree ? fast_tree_first + fast_tree_count : 0;
-        for (size_t i = 0; i < f.qnodes.size(); ++i) {
-            if (f.fast_tree && i >= fast_tree_first && i < fast_end) continue;          // came with their 8-bit form
-            quantise_node(f.qnodes[i], f.cqnodes[i]);
-            if (qdepth[i] < 4)
-                for (int j = 0; j < 4; ++j) {
-                    if (f.qnodes[i].child[j] == RT_REF_NONE) continue;
-                    const double r = quantised_area_ratio(f.qnodes[i], f.cqnodes[i], j);
-                    if (r >= 0.0) { ratio_sum += r; ++ratio_n; }
-                }
-        }
+        const size_t total = f.qnodes.size();
+        // (the nodes near a root, whose ratios are summed, are few: they are done in order by this thread; the rest in parallel)
+        auto quantise = [&](size_t lo, size_t hi, bool near_root) {
+            for (size_t i = lo; i < hi; ++i) {
+                if (f.fast_tree && i >= fast_tree_first && i < fast_end) continue;          // came with their 8-bit form
+                if ((qdepth[i] < 4) != near_root) continue;
+                quantise_node(f.qnodes[i], f.cqnodes[i]);
+                if (near_root)
+                    for (int j = 0; j < 4; ++j) {
+                        if (f.qnodes[i].child[j] == RT_REF_NONE) continue;
+                        const double r = quantised_area_ratio(f.qnodes[i], f.cqnodes[i], j);
+                        if (r >= 0.0) { ratio_sum += r; ++ratio_n; }
+                    }
+            }
+        };
+        const int parts = total >= (1u << 16) ? (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency())) : 1;
+        std::vector<std::future<void>> jobs;
+        for (int p = 1; p < parts; ++p)
+            jobs.push_back(std::async(std::launch::async, [&, p]() { quantise(total * (size_t)p / (size_t)parts, total * (size_t)(p + 1) / (size_t)parts, false); }));
+        quantise(0, total / (size_t)parts, false);
+        for (auto& j : jobs) j.get();
+        quantise(0, total, true);
         return ratio_n ? ratio_sum / (double)ratio_n : 1.0;
     }
 
@@ -1065,6 +1078,26 @@ struct Flattener {
             if ((int64_t)root == fast_candidate) {
                 // a mesh gets a tree built for the nearest-first traversal instead of the collapse (first: a tree that was
                 // built beside the reference BVHs brings its arrays along as the scene's first wide nodes)
+                if (early.started && early.root == root && f.qnodes.empty() && !getenv("MI355RT_NO_BUILD_OVERLAP")) {
+                    // That tree is still being built on its own threads, and the exact-cull tree needs nothing but the
+                    // reference's nodes: collapse it meanwhile, from index 0, and move it behind the other afterwards.
+                    if (int rce = exact_cull_tree(root)) return rce;
+                    RawVec<QNode> held;
+                    std::vector<uint8_t> held_depth;
+                    held.swap(f.qnodes);
+                    held_depth.swap(qdepth);
+                    if (int rcf = traversal_only_tree(root)) return rcf;
+                    if (f.qnodes.size() & 1u) add_empty_qnode(); // sibling groups of the moved tree stay on even indices
+                    const uint32_t shift = (uint32_t)f.qnodes.size();
+                    for (QNode& q : held)
+                        for (int j = 0; j < 4; ++j)
+                            if (q.child[j] != RT_REF_NONE && RT_REF_KIND(q.child[j]) == REF_QNODE) q.child[j] = make_ref(REF_QNODE, RT_REF_INDEX(q.child[j]) + shift);
+                    f.qnodes.insert(f.qnodes.end(), held.begin(), held.end());
+                    qdepth.insert(qdepth.end(), held_depth.begin(), held_depth.end());
+                    f.exact_first += shift;
+                    f.exact_root = make_ref(REF_QNODE, RT_REF_INDEX(f.exact_root) + shift);
+                    continue;
+                }
                 if (int rcf = traversal_only_tree(root)) return rcf;
                 if (f.fast_tree) {
                     if (int rce = exact_cull_tree(root)) return rce;
