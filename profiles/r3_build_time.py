@@ -5,7 +5,7 @@ import ray_tracer_amd as rt
 from ray_tracer_amd import scenes
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
 kind = sys.argv[2] if len(sys.argv) > 2 else "soup"
-w = scenes.triangle_soup_scene(n, seed=2) if kind == "soup" else scenes.closed_mesh_scene(n)
+w = scenes.triangle_soup_scene(n, seed=2) if kind == "soup" else rt.Mesh(scenes.icosphere_mesh(subdiv=8), rt.Lambertian(rt.Color(.5, .5, .5)))  # closed mesh: 1,310,720 triangles
 desc = rt.SceneDesc.from_world(w)
 gpu = torch.cuda.is_available()
 for i in range(3):

@@ -60,7 +60,10 @@ inline FBox meet(const FBox& a, const FBox& b) {
     for (int k = 0; k < 3; ++k) { r.lo[k] = std::max(a.lo[k], b.lo[k]); r.hi[k] = std::min(a.hi[k], b.hi[k]); }
     return r;
 }
-struct FRef { FBox b; uint32_t tri; };
+// One cache line per reference: its box, its triangle, and the triangle's vertices in f32 for the search among
+// candidate planes (which would otherwise fetch the 128-byte f64 triangle record, a cache miss per reference and level).
+struct alignas(64) FRef { FBox b; uint32_t tri; float v[3][3]; };
+static_assert(sizeof(FRef) == 64, "one line per reference");
 
 inline float down32(double x) { float f = (float)x; if ((double)f > x) f = std::nextafterf(f, -FINF); return f; }
 inline float up32(double x) { float f = (float)x; if ((double)f < x) f = std::nextafterf(f, FINF); return f; }
@@ -87,6 +90,7 @@ struct SpaBins {
 };
 
 struct Builder {
+    std::atomic<long long> ns_a{0}, ns_b{0}, ns_c{0}, ns_d{0}, ns_sweep{0}, ns_search{0};
     const DTri* tris = nullptr;
     const uint32_t* ids = nullptr; // triangle numbers in DScene::tris
     std::unique_ptr<BNode[]> pool;
@@ -106,7 +110,7 @@ struct Builder {
         fn(0, n / (size_t)parts, 0);
         for (auto& j : jobs) j.get();
     }
-    int parts_for(size_t n) const { return n >= CHUNK_MIN ? std::max(1, std::min(max_tasks + 1, 8)) : 1; }
+    int parts_for(size_t n) const { return n >= CHUNK_MIN ? std::max(1, std::min(max_tasks + 1, n >= 4 * CHUNK_MIN ? 16 : 8)) : 1; }
 
     // Box of the part of triangle t with lo <= x[axis] <= hi, rounded outward to f32 (the clipping arithmetic's own
     // rounding is covered by a relative pad far below the f32 step).
@@ -144,9 +148,8 @@ struct Builder {
 
     // The same box in plain f32 arithmetic, for the search among candidate planes (where a box that is off by a rounding
     // only changes an estimate); the split that is finally made uses clip().
-    FBox clip_estimate(uint32_t t, int axis, float lo, float hi) const {
-        const DTri& T = tris[ids[t]];
-        const float v[3][3] = {{(float)T.v0[0], (float)T.v0[1], (float)T.v0[2]}, {(float)T.v1[0], (float)T.v1[1], (float)T.v1[2]}, {(float)T.v2[0], (float)T.v2[1], (float)T.v2[2]}};
+    static FBox clip_estimate(const FRef& ref, int axis, float lo, float hi) {
+        const float (*v)[3] = ref.v;
         FBox r; r.reset();
         for (int i = 0; i < 3; ++i) {
             const float* a = v[i];
@@ -167,8 +170,20 @@ struct Builder {
         return r;
     }
 
+    // Node numbers are handed out in blocks of NODE_BLOCK per thread: one shared counter incremented for each of three
+    // million nodes by sixteen threads is a cache line that never rests.
+    static constexpr uint32_t NODE_BLOCK = 512;
+    static uint64_t next_serial() { static std::atomic<uint64_t> n{0}; return ++n; }
+    const uint64_t serial = next_serial();
     uint32_t alloc() {
-        const uint32_t i = next.fetch_add(1);
+        thread_local uint64_t owner = 0; // (a builder's number, not its address: the next build may stand where this one stood)
+        thread_local uint32_t at = 0, end = 0;
+        if (owner != serial || at == end) {
+            owner = serial;
+            at = next.fetch_add(NODE_BLOCK);
+            end = at + NODE_BLOCK;
+        }
+        const uint32_t i = at++;
         if (i >= pool_size) { overflow = true; return (uint32_t)pool_size - 1; }
         return i;
     }
@@ -187,9 +202,27 @@ struct Builder {
         }
     }
 
+    // Up to four subtrees: every large one but the last as a task of its own while threads are free.
+    template <class Size, class Fn>
+    void fan(int n, Size size, Fn fn) {
+        std::future<void> futs[3];
+        int started = 0;
+        for (int j = 0; j < n; ++j) {
+            if (j + 1 < n && size(j) >= TASK_MIN && tasks.load(std::memory_order_relaxed) < max_tasks) {
+                ++tasks;
+                futs[started++] = std::async(std::launch::async, [this, &fn, j]() { fn(j); --tasks; });
+            } else {
+                fn(j);
+            }
+        }
+        for (int k = 0; k < started; ++k) futs[k].get();
+    }
+
     // ---------------------------------------------------------------------------------------------- pass 1: binary tree
     // refs[0, n) belong to this call and are permuted in place.
     uint32_t build(FRef* refs, size_t n, int depth) {
+        static const bool prof = getenv("MI355RT_TREE_PROFILE") != nullptr;
+        const auto t_node = std::chrono::steady_clock::now();
         const uint32_t me = alloc();
         BNode& node = pool[me];
         node.left = node.right = -1;
@@ -213,8 +246,10 @@ struct Builder {
             for (int p = 0; p < parts; ++p) { nb.grow(pn[p]); cb.grow(pc[p]); }
         }
         node.b = nb;
+        const auto t_a = std::chrono::steady_clock::now();
+        if (prof) ns_a += std::chrono::duration_cast<std::chrono::nanoseconds>(t_a - t_node).count();
         size_t n_left = 0;             // in-place result: refs[0, n_left) | refs[n_left, n)
-        std::vector<FRef> copy;        // a spatial split's references: left part, then right part
+        RawVec<FRef> copy;             // a spatial split's references: left part, then right part (written by the threads that fill it)
         size_t copy_left = 0;
         bool done = false;
         if (n > 2 && n <= SWEEP_MAX && depth < 60) {
@@ -235,6 +270,7 @@ struct Builder {
                 }
                 done = n_left > 0;
             }
+            if (prof) ns_sweep += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_a).count();
         } else if (n > SWEEP_MAX && depth < 60) {
             // object split: surface-area heuristic over BINS bins of the centres, all three axes in one pass
             float sc[3];
@@ -266,6 +302,8 @@ struct Builder {
                     if (cost < best) { best = cost; best_axis = a; best_bin = i; best_l = acc; best_r = rb[i]; }
                 }
             }
+            const auto t_b = std::chrono::steady_clock::now();
+            if (prof) ns_b += std::chrono::duration_cast<std::chrono::nanoseconds>(t_b - t_a).count();
             // Spatial split along the same axis, where the halves of the object split overlap.  Only in nodes of
             // SPATIAL_MIN references or more: measured on the 2^20-triangle soup, the splits that pay are those near the
             // top of the tree (with them in every node a ray makes 27.55 node steps, from 64 references on 27.60, from
@@ -289,7 +327,7 @@ struct Builder {
                             ++s.en[b0]; ++s.ex[b1];
                             if (b0 == b1) { s.box[b0].grow(r.b); continue; }
                             for (int b = b0; b <= b1; ++b) {
-                                const FBox c = meet(clip_estimate(r.tri, a, nb.lo[a] + (float)b * w, nb.lo[a] + (float)(b + 1) * w), r.b);
+                                const FBox c = meet(clip_estimate(r, a, nb.lo[a] + (float)b * w, nb.lo[a] + (float)(b + 1) * w), r.b);
                                 if (c.valid()) s.box[b].grow(c);
                             }
                         }
@@ -309,41 +347,65 @@ struct Builder {
                     }
                     spatial = s_cost < best;
                 }
+                if (prof) { const auto t_s = std::chrono::steady_clock::now(); ns_search += std::chrono::duration_cast<std::chrono::nanoseconds>(t_s - t_b).count(); }
                 if (spatial) {
-                    std::vector<FRef> right;
-                    copy.reserve(n + n / 4); right.reserve(n / 2 + n / 8);
-                    int64_t added = 0;
-                    for (size_t i = 0; i < n; ++i) {
-                        const FRef& r = refs[i];
-                        if (r.b.hi[a] <= s_pos) copy.push_back(r);
-                        else if (r.b.lo[a] >= s_pos) right.push_back(r);
-                        else {
-                            FRef l = r, rr = r;
-                            l.b = meet(clip(r.tri, a, -1e300, (double)s_pos), r.b);
-                            rr.b = meet(clip(r.tri, a, (double)s_pos, 1e300), r.b);
-                            const bool lv = l.b.valid(), rv = rr.b.valid();
-                            if (lv) copy.push_back(l);
-                            if (rv) right.push_back(rr);
-                            if (lv && rv) ++added;
-                            if (!lv && !rv) copy.push_back(r); // (cannot happen for a box that straddles the plane; never lose a reference)
+                    // every piece of the range sorts its references into a left and a right list; the lists are joined in
+                    // the order of the pieces, i.e. in the order one thread would have produced
+                    std::vector<std::vector<FRef>> lefts(parts), rights(parts);
+                    std::vector<int64_t> addeds(parts, 0);
+                    chunks(n, parts, [&](size_t lo, size_t hi, int p) {
+                        std::vector<FRef>& left = lefts[p];
+                        std::vector<FRef>& right = rights[p];
+                        left.reserve((hi - lo) / 2 + (hi - lo) / 8); right.reserve((hi - lo) / 2 + (hi - lo) / 8);
+                        int64_t added = 0;
+                        for (size_t i = lo; i < hi; ++i) {
+                            const FRef& r = refs[i];
+                            if (r.b.hi[a] <= s_pos) left.push_back(r);
+                            else if (r.b.lo[a] >= s_pos) right.push_back(r);
+                            else {
+                                FRef l = r, rr = r;
+                                l.b = meet(clip(r.tri, a, -1e300, (double)s_pos), r.b);
+                                rr.b = meet(clip(r.tri, a, (double)s_pos, 1e300), r.b);
+                                const bool lv = l.b.valid(), rv = rr.b.valid();
+                                if (lv) left.push_back(l);
+                                if (rv) right.push_back(rr);
+                                if (lv && rv) ++added;
+                                if (!lv && !rv) left.push_back(r); // (cannot happen for a box that straddles the plane; never lose a reference)
+                            }
                         }
-                    }
-                    if (copy.empty() || right.empty() || copy.size() == n || right.size() == n) { copy.clear(); }
-                    else {
-                        copy_left = copy.size();
-                        copy.insert(copy.end(), right.begin(), right.end());
+                        addeds[p] = added;
+                    });
+                    size_t n_l = 0, n_r = 0;
+                    int64_t added = 0;
+                    for (int p = 0; p < parts; ++p) { n_l += lefts[p].size(); n_r += rights[p].size(); added += addeds[p]; }
+                    if (n_l != 0 && n_r != 0 && n_l != n && n_r != n) {
+                        copy.resize(n_l + n_r);
+                        std::vector<size_t> at_l(parts), at_r(parts);
+                        size_t al = 0, ar = n_l;
+                        for (int p = 0; p < parts; ++p) { at_l[p] = al; at_r[p] = ar; al += lefts[p].size(); ar += rights[p].size(); }
+                        chunks((size_t)parts, parts, [&](size_t lo, size_t hi, int) {
+                            for (size_t p = lo; p < hi; ++p) {
+                                std::copy(lefts[p].begin(), lefts[p].end(), copy.begin() + (std::ptrdiff_t)at_l[p]);
+                                std::copy(rights[p].begin(), rights[p].end(), copy.begin() + (std::ptrdiff_t)at_r[p]);
+                            }
+                        });
+                        copy_left = n_l;
                         spare.fetch_sub(added, std::memory_order_relaxed);
                         done = true;
                     }
                 }
             }
+            const auto t_c = std::chrono::steady_clock::now();
+            if (prof) ns_c += std::chrono::duration_cast<std::chrono::nanoseconds>(t_c - t_b).count();
             if (!done && best_axis >= 0) {
                 const int a = best_axis;
                 n_left = (size_t)(std::partition(refs, refs + n, [&](const FRef& r) { return bin_of(r, a) < best_bin; }) - refs);
                 done = n_left > 0 && n_left < n;
             }
+            if (prof) ns_d += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_c).count();
         }
         if (!done) n_left = n / 2; // two references, all centres equal, or too deep: halve
+        if (getenv("MI355RT_TREE_PROFILE") && n >= CHUNK_MIN) std::fprintf(stderr, "top node depth %d n %zu: %.4f s (%s)\n", depth, n, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_node).count(), copy.empty() ? "object" : "spatial");
         FRef* lp = copy.empty() ? refs : copy.data();
         const size_t ln = copy.empty() ? n_left : copy_left, rn = copy.empty() ? n - n_left : copy.size() - copy_left;
         FRef* rp = lp + ln;
@@ -384,11 +446,7 @@ struct Builder {
         int32_t need[4] = {0, 0, 0, 0};
         int inner = 0;
         for (int j = 0; j < nk; ++j) inner += pool[kids[j]].left >= 0 ? 1 : 0;
-        if (inner >= 2 && pool[v].leaves >= TASK_MIN) {
-            both(pool[kids[0]].leaves, [&]() { need[0] = count(kids[0]); }, [&]() { for (int j = 1; j < inner; ++j) need[j] = count(kids[j]); });
-        } else {
-            for (int j = 0; j < inner; ++j) need[j] = count(kids[j]);
-        }
+        fan(inner, [&](int j) { return (size_t)pool[kids[j]].leaves; }, [&](int j) { need[j] = count(kids[j]); });
         for (int j = 0; j < inner; ++j) { wide += pool[kids[j]].wide; deepest = std::max(deepest, need[j]); }
         pool[v].wide = wide;
         return (nk - 1) + deepest; // up to nk - 1 siblings stay deferred while one child is walked
@@ -447,12 +505,8 @@ struct Builder {
             next_at += pool[kids[j]].wide - 1u;
             next_leaves += pool[kids[j]].leaves;
         }
-        if (inner >= 2 && pool[v].leaves >= TASK_MIN) {
-            both(pool[kids[0]].leaves, [&]() { emit(kids[0], kids_at, below_at[0], below_leaves[0], depth + 1); },
-                 [&]() { for (int j = 1; j < inner; ++j) emit(kids[j], kids_at + (uint32_t)j, below_at[j], below_leaves[j], depth + 1); });
-        } else {
-            for (int j = 0; j < inner; ++j) emit(kids[j], kids_at + (uint32_t)j, below_at[j], below_leaves[j], depth + 1);
-        }
+        fan(inner, [&](int j) { return (size_t)pool[kids[j]].leaves; },
+            [&](int j) { emit(kids[j], kids_at + (uint32_t)j, below_at[j], below_leaves[j], depth + 1); });
     }
 };
 
@@ -466,7 +520,7 @@ int build_fast_tree(const DTri* tris, FlatScene& f, std::vector<uint8_t>& qdepth
     B.tris = tris;
     B.ids = tri_ids;
     const uint64_t extra = n;                       // spatial splits may add up to one more reference per triangle
-    B.pool_size = 2 * (n + extra) + 64;
+    B.pool_size = 2 * (n + extra) + 64 + (size_t)Builder::NODE_BLOCK * 4096; // (blocks of node numbers that threads leave half used)
     B.pool.reset(new BNode[B.pool_size]);
     B.spare = (int64_t)extra;
     B.max_tasks = (int)std::min<unsigned>(15u, std::max(1u, std::thread::hardware_concurrency()) - 1u);
@@ -481,6 +535,7 @@ int build_fast_tree(const DTri* tris, FlatScene& f, std::vector<uint8_t>& qdepth
                 const DTri& T = B.tris[tri_ids[i]];
                 FRef& r = refs[i];
                 r.tri = (uint32_t)i;
+                for (int k = 0; k < 3; ++k) { r.v[0][k] = (float)T.v0[k]; r.v[1][k] = (float)T.v1[k]; r.v[2][k] = (float)T.v2[k]; }
                 for (int k = 0; k < 3; ++k) {
                     double l = std::fmin(std::fmin(T.v0[k], T.v1[k]), T.v2[k]), h = std::fmax(std::fmax(T.v0[k], T.v1[k]), T.v2[k]);
                     if (h - l < 0.0001) { l -= 0.00005; h += 0.00005; } // as the reference pads thin boxes (aabb.rs:125-136)
@@ -541,6 +596,8 @@ int build_fast_tree(const DTri* tris, FlatScene& f, std::vector<uint8_t>& qdepth
         std::fprintf(stderr, "[mi355rt] traversal-only tree: %llu triangles, %llu references, %llu wide nodes; set-up %.3f s, binary tree %.3f s, records %.3f s (%d tasks)\n",
                      (unsigned long long)n, (unsigned long long)leaves, (unsigned long long)wide, std::chrono::duration<double>(t_1 - t_0).count(),
                      std::chrono::duration<double>(t_2 - t_1).count(), std::chrono::duration<double>(t_3 - t_2).count(), B.max_tasks);
+        if (getenv("MI355RT_TREE_PROFILE")) std::fprintf(stderr, "[mi355rt]   binary tree, thread-seconds: bounds %.3f, object bins %.3f, spatial search+apply %.3f (search %.3f), partition %.3f, sweeps %.3f\n",
+                                           B.ns_a * 1e-9, B.ns_b * 1e-9, B.ns_c * 1e-9, B.ns_search * 1e-9, B.ns_d * 1e-9, B.ns_sweep * 1e-9);
         std::fprintf(stderr, "[mi355rt]   records: count %.3f s, arrays %.3f s, emit %.3f s, measures %.3f s\n", std::chrono::duration<double>(t_2a - t_2).count(),
                      std::chrono::duration<double>(t_2b - t_2a).count(), std::chrono::duration<double>(t_2c - t_2b).count(), std::chrono::duration<double>(t_3 - t_2c).count());
     }

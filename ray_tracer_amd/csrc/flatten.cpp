@@ -18,6 +18,7 @@
 #include "quantise.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -298,17 +299,27 @@ struct Flattener {
             o.area = len3(n);
             o.mat = s.mat; o._pad = 0;
         }
-        f.tris.resize(d->n_triangles);
-        for (uint64_t i = 0; i < d->n_triangles; ++i) { // triangle.rs:122-125
-            const rt_triangle& s = d->triangles[i];
-            if (!mat_ok(s.mat)) return fail(RT_E_INVALID, "triangle: material out of range");
-            DTri& o = f.tris[i];
-            V3 v0 = v3(s.v0), v1 = v3(s.v1), v2 = v3(s.v2);
-            put(o.v0, v0); put(o.v1, v1); put(o.v2, v2);
-            put(o.n, unit3(cross3(sub(v1, v0), sub(v2, v0))));
-            o.mat = s.mat; o._pad0 = 0;
-            o._pad[0] = o._pad[1] = o._pad[2] = 0.0;
-        }
+        f.tris.resize(d->n_triangles); // (left uninitialised: every record is written below, by the thread that owns its part)
+        const uint64_t nt = d->n_triangles;
+        const int parts = nt >= (1u << 16) ? (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency())) : 1;
+        std::atomic<bool> bad_mat{false};
+        auto fill = [&](uint64_t lo, uint64_t hi) {
+            for (uint64_t i = lo; i < hi; ++i) { // triangle.rs:122-125
+                const rt_triangle& s = d->triangles[i];
+                if (!mat_ok(s.mat)) { bad_mat = true; return; }
+                DTri& o = f.tris[i];
+                V3 v0 = v3(s.v0), v1 = v3(s.v1), v2 = v3(s.v2);
+                put(o.v0, v0); put(o.v1, v1); put(o.v2, v2);
+                put(o.n, unit3(cross3(sub(v1, v0), sub(v2, v0))));
+                o.mat = s.mat; o._pad0 = 0;
+                o._pad[0] = o._pad[1] = o._pad[2] = 0.0;
+            }
+        };
+        std::vector<std::future<void>> jobs;
+        for (int p = 1; p < parts; ++p) jobs.push_back(std::async(std::launch::async, fill, nt * (uint64_t)p / (uint64_t)parts, nt * (uint64_t)(p + 1) / (uint64_t)parts));
+        fill(0, nt / (uint64_t)parts);
+        for (auto& j : jobs) j.get();
+        if (bad_mat) return fail(RT_E_INVALID, "triangle: material out of range");
         return RT_OK;
     }
 

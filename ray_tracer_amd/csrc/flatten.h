@@ -36,7 +36,7 @@ struct FlatScene {
     RawVec<CQNode> cqnodes;            // the same nodes with 8-bit boxes (same indices); empty when the grid would be too coarse
     std::vector<DSphere> spheres;
     std::vector<DQuad> quads;
-    std::vector<DTri> tris;
+    RawVec<DTri> tris;
     std::vector<DList> lists;
     std::vector<uint32_t> list_items;
     std::vector<DXform> xforms;

@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <future>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -161,8 +162,24 @@ int upload(rt_scene* s, const std::vector<T, A>& v, const T** out) {
     HIP_TRY(hipMalloc(&p, bytes));
     s->allocs.push_back(p);
     s->device_bytes += bytes;
-    if (!v.empty()) HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    // the large arrays are copied later, side by side (finish_uploads): a copy from pageable memory runs at a fraction of the link's rate
+    if (v.size() * sizeof(T) >= (8u << 20)) s->pending_uploads.push_back({p, v.data(), v.size() * sizeof(T)});
+    else if (!v.empty()) HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
     *out = static_cast<const T*>(p);
+    return RT_OK;
+}
+
+int finish_uploads(rt_scene* s) {
+    std::vector<std::future<hipError_t>> jobs;
+    for (const auto& u : s->pending_uploads)
+        jobs.push_back(std::async(std::launch::async, [s, u]() {
+            hipError_t e = hipSetDevice(s->device);
+            return e != hipSuccess ? e : hipMemcpy(u.dst, u.src, u.bytes, hipMemcpyHostToDevice);
+        }));
+    hipError_t first = hipSuccess;
+    for (auto& j : jobs) { const hipError_t e = j.get(); if (first == hipSuccess) first = e; }
+    s->pending_uploads.clear();
+    if (first != hipSuccess) return set_err(RT_E_HIP, std::string("upload of the scene arrays: ") + hipGetErrorString(first));
     return RT_OK;
 }
 
@@ -332,6 +349,7 @@ int upload_scene(rt_scene* s) {
     if ((rc = upload(s, f.perlins, &d.perlins))) return rc;
     if ((rc = upload(s, f.lights, &d.lights))) return rc;
     if ((rc = upload(s, f.ebox, &d.ebox))) return rc;
+    if ((rc = finish_uploads(s))) return rc;
     d.exact_first = f.exact_first;
     d.n_xforms = (uint32_t)f.xforms.size(); d.n_perlins = (uint32_t)f.perlins.size();
     d.world = f.world; d.n_lights = f.n_lights; d.lights_is_list = f.lights_is_list; d.q_extent = f.q_extent; d.uses_uv = f.uses_uv ? 1u : 0u; d.world_rest = f.world_rest;

@@ -172,6 +172,8 @@ struct rt_scene {
     bool host_only = false;
     int device = -1;
     std::vector<void*> allocs;
+    struct PendingUpload { void* dst; const void* src; size_t bytes; };
+    std::vector<PendingUpload> pending_uploads; // large arrays whose copy to the device is still to be made (rt_scene_create only)
     uint64_t device_bytes = 0;
     unsigned long long* d_counters = nullptr;
     unsigned long long* h_counters = nullptr; // pinned
