@@ -534,3 +534,23 @@ def test_obj_file_through_the_c_abi(tmp_path):
     empty = tmp_path / "empty.obj"
     empty.write_text("# nothing\n")
     assert load_obj(str(empty)).shape == (0, 3, 3)
+
+
+def test_traversal_only_tree_does_not_depend_on_the_threads_that_build_it():
+    """The traversal-only tree is built by tasks that run on whatever threads are free and take their node numbers in
+    blocks: the records must come out the same every time, byte for byte (wide nodes, packed nodes, exact-cull tree
+    behind them), large enough a mesh for the parallel paths (chunked binning from 2^17 references on, subtrees as tasks
+    from 2^13 on)."""
+    m = rt.Lambertian(rt.Color(.5, .5, .5))
+    tri = scenes.triangle_soup(150000, seed=29, edge=0.03)
+    first = None
+    for _ in range(3):
+        s = rt.Scene(rt.Mesh(tri, m), host_only=True)
+        packed, overlap = s.packed_nodes()
+        got = (s.wide_nodes().tobytes(), packed.tobytes(), overlap, s.fast_tree_info())
+        s.close()
+        if first is None:
+            first = got
+            assert got[3][2] and got[3][1] > len(tri)  # a traversal-only tree with spatial splits
+        else:
+            assert got == first
