@@ -211,7 +211,10 @@ def main() -> None:
 
     # ------------------------------------------------------------------ the frame partitioned over the ranks + one reduce
     if dist is not None and not args.no_render:
-        fig = _multi_gpu_render(rt, F, scenes, parallel, torch, dist, dev, stream, args.frame_strata * world_size)
+        try:
+            fig = _multi_gpu_render(rt, F, scenes, parallel, torch, dist, dev, stream, args.frame_strata * world_size)
+        except Exception as e:  # noqa: BLE001 -- the closest-hit line above has been measured: report it whatever happens to this leg
+            fig = {"error": f"{type(e).__name__}: {e}"}
         if rank == 0:
             out["multi_gpu_render"] = fig
     if rank == 0:
