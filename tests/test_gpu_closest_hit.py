@@ -653,6 +653,54 @@ def test_exact_cull_on_f32_nodes_with_and_without_the_short_cut(monkeypatch):
         assert np.mean(got["prim"][:n] != want["prim"]) < 0.01
 
 
+def test_traversal_only_tree_on_awkward_meshes():
+    """Meshes the surface-area heuristic and the spatial splits have to cope with, each large enough (>= 1024
+    triangles) to get the traversal-only tree, each against the oracle in the nearest-first mode and in the reference's
+    order: every triangle the same one (all centres and boxes equal: no split separates anything), a few triangles as
+    large as the scene among thousands of small ones (they straddle every plane), coplanar axis-aligned triangles (boxes
+    of zero thickness, padded as aabb.rs:125-136 pads them), needles a thousand times longer than wide, a mesh of
+    exactly 1024 triangles and one of 1023 (which keeps the collapse of the reference's tree)."""
+    m = rt.Lambertian(rt.Color(.5, .5, .5))
+    g = np.random.default_rng(101)
+    soup = scenes.triangle_soup(4000, seed=61, edge=0.05)
+    cases = {}
+    cases["identical"] = (np.repeat(soup[:1], 2048, axis=0), 0.0)
+    mixed = soup.copy()
+    mixed[:6] = g.uniform(-0.5, 1.5, (6, 3, 3))
+    cases["huge among small"] = (mixed, 0.02)
+    flat = soup[:3000].copy()
+    flat[:, :, 1] = np.round(flat[:, :1, 1] * 8) / 8          # eight horizontal planes
+    cases["coplanar"] = (flat, 0.05)
+    a = g.uniform(0, 1, (2500, 3))
+    dirs = g.normal(size=(2500, 3)); dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    side = np.cross(dirs, g.normal(size=(2500, 3))); side /= np.linalg.norm(side, axis=1, keepdims=True)
+    cases["needles"] = (np.stack([a, a + 0.4 * dirs, a + 0.4 * dirs + 4e-4 * side], axis=1), 0.02)
+    cases["1024"] = (soup[:1024], 0.02)
+    cases["1023"] = (soup[:1023], 0.02)
+    o, d, _ = scenes.incoherent_rays(30000, [-0.1, 1.1, -0.1, 1.1, -0.1, 1.1], seed=62)
+    aim = soup[g.integers(0, len(soup), 3000)].mean(axis=1)   # some rays aimed at triangle centres
+    o[:3000] = aim - d[:3000] * 0.7
+    for name, (tri, max_ties) in cases.items():
+        desc = rt.SceneDesc.from_world(rt.Mesh(np.ascontiguousarray(tri), m))
+        s = rt.Scene(desc, host_only=True)
+        assert s.fast_tree_info()[2] == (len(tri) >= 1024), name
+        s.close()
+        if name == "identical":  # every hit is a 2048-fold tie: only t can be compared, in either order
+            gpu, cpu = rt.Scene(desc), O.OracleScene(desc)
+            w = g.dirichlet([1.0, 1.0, 1.0], size=5000)
+            oi = w @ tri[0] - d[:5000] * 0.7   # towards points of the one triangle
+            oi[::10] = o[:5000:10]             # and some that miss it
+            want = cpu.closest_hit(oi, d[:5000], nthreads=8)
+            assert (want["prim"] != F.RT_REF_NONE).sum() > 4000
+            for flags in (0, F.RT_HIT_ORDERED, F.RT_HIT_ORDERED | F.RT_HIT_EXACT_CULL):
+                got = gpu.closest_hit(oi, d[:5000], flags=flags)
+                assert np.array_equal(got["t"].view(np.uint64), want["t"].view(np.uint64)), flags
+            gpu.close()
+            continue
+        for flags in (0, F.RT_HIT_ORDERED, F.RT_HIT_ORDERED | F.RT_HIT_EXACT_CULL):
+            compare(desc, o, d, min_hits=200, flags=flags, max_ties=max(max_ties, 0.02))
+
+
 def test_one_scene_from_several_threads():
     """The reference calls world.hit on one world from every rayon worker (camera.rs:99).  Several host threads call
     rt_closest_hit on ONE scene at once (ctypes releases the interpreter lock during the call): the library puts the
