@@ -546,7 +546,9 @@ int build_fast_tree(const DTri* tris, FlatScene& f, std::vector<uint8_t>& qdepth
             }
             roots[p] = root;
         });
-        if (bad) { err = "fast tree: non-finite triangle"; return RT_E_INVALID; }
+        // (coordinates that are not finite, or whose boxes overflow f32: not this builder's to judge -- the scene keeps the
+        // collapse of the reference's tree, and whatever the reference's own rules say about such a triangle applies there)
+        if (bad) { err = "fast tree: a triangle's box is not finite in f32"; return RT_E_UNSUPPORTED; }
         FBox root; root.reset();
         for (const FBox& b : roots) root.grow(b);
         B.root_area = std::max(root.area(), 1e-30f);

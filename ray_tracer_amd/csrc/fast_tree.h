@@ -22,7 +22,8 @@ struct FastTreeResult {
 // as f.pnodes / f.ptris (left empty when the mesh is too large for their 32-bit byte offsets).  Reads nothing of `f`
 // but the sizes of those arrays, so `f` may be a scene of its own that the caller merges later.  Leaves are
 // RT_REF_TRI | tri_ids[i]; a triangle may be the child of several nodes, each time with the box of the part of it that
-// lies on that node's side of the spatial splits above it.  Returns RT_OK or a negative RT_E_* code with `err` set.
+// lies on that node's side of the spatial splits above it.  Returns RT_OK or a negative RT_E_* code with `err` set;
+// RT_E_UNSUPPORTED means that this mesh gets no such tree (a box that is not finite in f32) and nothing was appended.
 int build_fast_tree(const DTri* tris, FlatScene& f, std::vector<uint8_t>& qdepth, const uint32_t* tri_ids, uint64_t n, FastTreeResult& out, std::string& err);
 
 } // namespace rt

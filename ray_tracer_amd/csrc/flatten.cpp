@@ -754,6 +754,7 @@ struct Flattener {
             // built beside the reference BVHs (start_early_fast_tree): its arrays become the first nodes of the scene's
             const int rc = early.done.get();
             early.started = false;
+            if (rc == RT_E_UNSUPPORTED) { early.scene = FlatScene(); return RT_OK; } // (see build_fast_tree: not an error of the scene)
             if (rc) return fail(rc, early.err);
             f.qnodes = std::move(early.scene.qnodes);
             f.cqnodes = std::move(early.scene.cqnodes);
@@ -779,6 +780,7 @@ struct Flattener {
             std::string e;
             fast_tree_first = f.qnodes.size();
             const int rc = build_fast_tree(f.tris.data(), f, qdepth, ids.data(), ids.size(), res, e);
+            if (rc == RT_E_UNSUPPORTED) return RT_OK;
             if (rc) return fail(rc, e);
         }
         f.fast_root = make_ref(REF_QNODE, res.root);
@@ -1098,6 +1100,12 @@ struct Flattener {
                     held.swap(f.qnodes);
                     held_depth.swap(qdepth);
                     if (int rcf = traversal_only_tree(root)) return rcf;
+                    if (!f.fast_tree) {
+                        // no such tree after all (coordinates its f32 boxes cannot hold): the collapse of the reference's
+                        // tree serves, built below as for any other BVH, and the exact-cull tree behind it
+                        f.ebox.clear();
+                        f.exact_root = RT_REF_NONE; f.exact_first = f.exact_count = f.exact_stack = 0;
+                    } else {
                     if (f.qnodes.size() & 1u) add_empty_qnode(); // sibling groups of the moved tree stay on even indices
                     const uint32_t shift = (uint32_t)f.qnodes.size();
                     for (QNode& q : held)
@@ -1108,6 +1116,7 @@ struct Flattener {
                     f.exact_first += shift;
                     f.exact_root = make_ref(REF_QNODE, RT_REF_INDEX(f.exact_root) + shift);
                     continue;
+                    }
                 }
                 if (int rcf = traversal_only_tree(root)) return rcf;
                 if (f.fast_tree) {

@@ -656,7 +656,8 @@ def test_exact_cull_on_f32_nodes_with_and_without_the_short_cut(monkeypatch):
 def test_traversal_only_tree_on_awkward_meshes():
     """Meshes the surface-area heuristic and the spatial splits have to cope with, each large enough (>= 1024
     triangles) to get the traversal-only tree, each against the oracle in the nearest-first mode and in the reference's
-    order: every triangle the same one (all centres and boxes equal: no split separates anything), a few triangles as
+    order: every triangle the same one (all centres and boxes equal: no split separates anything), a vertex at 1e30 and
+    one at 1e308 (beyond f32: that mesh keeps the collapse of the reference's tree), a few triangles as
     large as the scene among thousands of small ones (they straddle every plane), coplanar axis-aligned triangles (boxes
     of zero thickness, padded as aabb.rs:125-136 pads them), needles a thousand times longer than wide, a mesh of
     exactly 1024 triangles and one of 1023 (which keeps the collapse of the reference's tree)."""
@@ -675,6 +676,12 @@ def test_traversal_only_tree_on_awkward_meshes():
     dirs = g.normal(size=(2500, 3)); dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
     side = np.cross(dirs, g.normal(size=(2500, 3))); side /= np.linalg.norm(side, axis=1, keepdims=True)
     cases["needles"] = (np.stack([a, a + 0.4 * dirs, a + 0.4 * dirs + 4e-4 * side], axis=1), 0.02)
+    far = soup.copy()
+    far[7, 1, 2] = 1e30                      # a vertex far outside everything: finite in f32, the scene's boxes become useless for 8-bit grids
+    cases["one vertex at 1e30"] = (far, 0.02)
+    farther = soup.copy()
+    farther[7, 1, 2] = 1e308                 # not finite in f32: no traversal-only tree, the scene must still be traced
+    cases["one vertex at 1e308"] = (farther, 0.02)
     cases["1024"] = (soup[:1024], 0.02)
     cases["1023"] = (soup[:1023], 0.02)
     o, d, _ = scenes.incoherent_rays(30000, [-0.1, 1.1, -0.1, 1.1, -0.1, 1.1], seed=62)
@@ -683,7 +690,7 @@ def test_traversal_only_tree_on_awkward_meshes():
     for name, (tri, max_ties) in cases.items():
         desc = rt.SceneDesc.from_world(rt.Mesh(np.ascontiguousarray(tri), m))
         s = rt.Scene(desc, host_only=True)
-        assert s.fast_tree_info()[2] == (len(tri) >= 1024), name
+        assert s.fast_tree_info()[2] == (len(tri) >= 1024 and name != "one vertex at 1e308"), name
         s.close()
         if name == "identical":  # every hit is a 2048-fold tie: only t can be compared, in either order
             gpu, cpu = rt.Scene(desc), O.OracleScene(desc)
