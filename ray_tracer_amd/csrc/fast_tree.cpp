@@ -32,6 +32,7 @@
 #include <memory>
 #include <thread>
 
+#include "host_parallel.h"
 #include "quantise.h"
 
 namespace rt {
@@ -103,12 +104,22 @@ struct Builder {
     std::atomic<bool> overflow{false};
 
     // Runs fn(begin, end, part) over `parts` near-equal pieces of [0, n), the first on this thread.
+    // The pieces are spread over this thread and as many more as the builder's budget of threads has left (`tasks`: the
+    // builder never runs more than max_tasks + 1 threads at a time, however many nodes bin their references at once).
     template <class Fn>
     void chunks(size_t n, int parts, Fn fn) {
-        std::vector<std::future<void>> jobs;
-        for (int p = 1; p < parts; ++p) jobs.push_back(std::async(std::launch::async, [=]() { fn(n * (size_t)p / (size_t)parts, n * (size_t)(p + 1) / (size_t)parts, p); }));
-        fn(0, n / (size_t)parts, 0);
-        for (auto& j : jobs) j.get();
+        const int helpers = take(parts - 1);
+        for_parts(parts, helpers, [&](int p) { fn(n * (size_t)p / (size_t)parts, n * (size_t)(p + 1) / (size_t)parts, p); });
+        tasks -= helpers;
+    }
+    // Reserves up to `want` threads of the budget; returns how many it got.
+    int take(int want) {
+        int cur = tasks.load(std::memory_order_relaxed);
+        for (;;) {
+            const int got = std::min(want, max_tasks - cur);
+            if (got <= 0) return 0;
+            if (tasks.compare_exchange_weak(cur, cur + got)) return got;
+        }
     }
     int parts_for(size_t n) const { return n >= CHUNK_MIN ? std::max(1, std::min(max_tasks + 1, n >= 4 * CHUNK_MIN ? 16 : 8)) : 1; }
 
@@ -191,15 +202,17 @@ struct Builder {
     // Two subtrees, the first as a task of its own when it is large and a thread is free.
     template <class FnL, class FnR>
     void both(size_t n_left, FnL left, FnR right) {
-        if (n_left >= TASK_MIN && tasks.load(std::memory_order_relaxed) < max_tasks) {
-            ++tasks;
-            auto fut = std::async(std::launch::async, [&]() { left(); --tasks; });
-            right();
-            fut.get();
-        } else {
-            left();
-            right();
+        std::future<void> fut;
+        if (n_left >= TASK_MIN && take(1) == 1) {
+            if (try_async(fut, [&]() { left(); --tasks; })) {
+                right();
+                fut.get();
+                return;
+            }
+            --tasks;
         }
+        left();
+        right();
     }
 
     // Up to four subtrees: every large one but the last as a task of its own while threads are free.
@@ -208,12 +221,11 @@ struct Builder {
         std::future<void> futs[3];
         int started = 0;
         for (int j = 0; j < n; ++j) {
-            if (j + 1 < n && size(j) >= TASK_MIN && tasks.load(std::memory_order_relaxed) < max_tasks) {
-                ++tasks;
-                futs[started++] = std::async(std::launch::async, [this, &fn, j]() { fn(j); --tasks; });
-            } else {
-                fn(j);
+            if (j + 1 < n && size(j) >= TASK_MIN && take(1) == 1) {
+                if (try_async(futs[started], [this, &fn, j]() { fn(j); --tasks; })) { ++started; continue; }
+                --tasks;
             }
+            fn(j);
         }
         for (int k = 0; k < started; ++k) futs[k].get();
     }
@@ -524,6 +536,7 @@ int build_fast_tree(const DTri* tris, FlatScene& f, std::vector<uint8_t>& qdepth
     B.pool.reset(new BNode[B.pool_size]);
     B.spare = (int64_t)extra;
     B.max_tasks = (int)std::min<unsigned>(15u, std::max(1u, std::thread::hardware_concurrency()) - 1u);
+    if (const char* e = getenv("MI355RT_TREE_THREADS")) B.max_tasks = std::max(0, std::min(255, atoi(e) - 1)); // (measurements)
     std::unique_ptr<FRef[]> refs(new FRef[n]);
     {
         const int parts = B.parts_for(n);

@@ -15,6 +15,7 @@
 // Nodes of one BVH are laid out in pre-order (left child = index + 1).
 #include "flatten.h"
 #include "fast_tree.h"
+#include "host_parallel.h"
 #include "quantise.h"
 
 #include <algorithm>
@@ -126,12 +127,9 @@ uint32_t build_bvh(std::vector<Item>& items, size_t start, size_t end, DNode* no
         auto less = [](const Key& a, const Key& b) { return a.k < b.k; };
         const size_t slices = (depth < 3 && span > (1u << 16)) ? (size_t)(8 >> depth) : 1;
         if (slices > 1) {
-            std::vector<std::future<void>> jobs;
             std::vector<size_t> cut(slices + 1);
             for (size_t s = 0; s <= slices; ++s) cut[s] = span * s / slices;
-            for (size_t s = 0; s < slices; ++s)
-                jobs.push_back(std::async(std::launch::async, [&, s]() { std::stable_sort(order.begin() + cut[s], order.begin() + cut[s + 1], less); }));
-            for (auto& j : jobs) j.get();
+            for_parts((int)slices, (int)slices - 1, [&](int s) { std::stable_sort(order.begin() + cut[s], order.begin() + cut[s + 1], less); });
             for (size_t width = 1; width < slices; width *= 2)
                 for (size_t s = 0; s + width < slices; s += 2 * width)
                     std::inplace_merge(order.begin() + cut[s], order.begin() + cut[s + width], order.begin() + cut[std::min(s + 2 * width, slices)], less);
@@ -150,9 +148,10 @@ uint32_t build_bvh(std::vector<Item>& items, size_t start, size_t end, DNode* no
         n.right = make_ref(RT_REF_NODE, (uint32_t)(base + right_at));
         uint32_t ml, mr;
         if (depth < 4 && span > 8192) { // the two halves are independent (bvh.rs:64-67 uses rayon::join)
-            auto fut = std::async(std::launch::async, [&]() { return build_bvh(items, start, mid, nodes, wnodes, base, left_at, depth + 1); });
+            std::future<uint32_t> fut;
+            const bool started = try_async(fut, [&]() { return build_bvh(items, start, mid, nodes, wnodes, base, left_at, depth + 1); });
             mr = build_bvh(items, mid, end, nodes, wnodes, base, right_at, depth + 1);
-            ml = fut.get();
+            ml = started ? fut.get() : build_bvh(items, start, mid, nodes, wnodes, base, left_at, depth + 1);
         } else {
             ml = build_bvh(items, start, mid, nodes, wnodes, base, left_at, depth + 1);
             mr = build_bvh(items, mid, end, nodes, wnodes, base, right_at, depth + 1);
@@ -315,10 +314,7 @@ struct Flattener {
                 o._pad[0] = o._pad[1] = o._pad[2] = 0.0;
             }
         };
-        std::vector<std::future<void>> jobs;
-        for (int p = 1; p < parts; ++p) jobs.push_back(std::async(std::launch::async, fill, nt * (uint64_t)p / (uint64_t)parts, nt * (uint64_t)(p + 1) / (uint64_t)parts));
-        fill(0, nt / (uint64_t)parts);
-        for (auto& j : jobs) j.get();
+        for_parts(parts, parts - 1, [&](int p) { fill(nt * (uint64_t)p / (uint64_t)parts, nt * (uint64_t)(p + 1) / (uint64_t)parts); });
         if (bad_mat) return fail(RT_E_INVALID, "triangle: material out of range");
         return RT_OK;
     }
@@ -819,11 +815,12 @@ struct Flattener {
         early.ids.resize((size_t)o->b);
         for (int32_t k = 0; k < o->b; ++k) early.ids[(size_t)k] = (uint32_t)(o->a + k);
         early.root = 0; // the world's BVH is the first one built: its nodes start the node array
-        early.started = true;
-        early.done = std::async(std::launch::async, [this]() {
+        // (no thread to be had: the tree is built later, in its turn, by traversal_only_tree)
+        early.started = try_async(early.done, [this]() {
             return build_fast_tree(f.tris.data(), early.scene, early.depth, early.ids.data(), early.ids.size(), early.res, early.err);
         });
     }
+    size_t quantised_first = 0, quantised_count = 0; // wide nodes whose 8-bit form exists already (the exact-cull tree, when it was built beside the traversal-only one)
     size_t fast_tree_first = 0, fast_tree_count = 0; // the traversal-only tree's nodes in qnodes (they come with their 8-bit and packed forms)
     double fast_ratio_sum = 0.0, fast_leaf_area = 0.0;
     uint64_t fast_ratio_n = 0;
@@ -866,6 +863,7 @@ struct Flattener {
         auto quantise = [&](size_t lo, size_t hi, bool near_root) {
             for (size_t i = lo; i < hi; ++i) {
                 if (f.fast_tree && i >= fast_tree_first && i < fast_end) continue;          // came with their 8-bit form
+                if (!near_root && i >= quantised_first && i < quantised_first + quantised_count) continue; // done while waiting for that tree
                 if ((qdepth[i] < 4) != near_root) continue;
                 quantise_node(f.qnodes[i], f.cqnodes[i]);
                 if (near_root)
@@ -877,11 +875,7 @@ struct Flattener {
             }
         };
         const int parts = total >= (1u << 16) ? (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency())) : 1;
-        std::vector<std::future<void>> jobs;
-        for (int p = 1; p < parts; ++p)
-            jobs.push_back(std::async(std::launch::async, [&, p]() { quantise(total * (size_t)p / (size_t)parts, total * (size_t)(p + 1) / (size_t)parts, false); }));
-        quantise(0, total / (size_t)parts, false);
-        for (auto& j : jobs) j.get();
+        for_parts(parts, parts - 1, [&](int p) { quantise(total * (size_t)p / (size_t)parts, total * (size_t)(p + 1) / (size_t)parts, false); });
         quantise(0, total, true);
         return ratio_n ? ratio_sum / (double)ratio_n : 1.0;
     }
@@ -1099,6 +1093,9 @@ struct Flattener {
                     std::vector<uint8_t> held_depth;
                     held.swap(f.qnodes);
                     held_depth.swap(qdepth);
+                    // (its 8-bit form too, with a few threads: the others are busy with the tree this one waits for)
+                    RawVec<CQNode> held_cq(held.size());
+                    for_parts(4, 3, [&](int p) { for (size_t i = held.size() * (size_t)p / 4; i < held.size() * (size_t)(p + 1) / 4; ++i) quantise_node(held[i], held_cq[i]); });
                     if (int rcf = traversal_only_tree(root)) return rcf;
                     if (!f.fast_tree) {
                         // no such tree after all (coordinates its f32 boxes cannot hold): the collapse of the reference's
@@ -1113,6 +1110,12 @@ struct Flattener {
                             if (q.child[j] != RT_REF_NONE && RT_REF_KIND(q.child[j]) == REF_QNODE) q.child[j] = make_ref(REF_QNODE, RT_REF_INDEX(q.child[j]) + shift);
                     f.qnodes.insert(f.qnodes.end(), held.begin(), held.end());
                     qdepth.insert(qdepth.end(), held_depth.begin(), held_depth.end());
+                    for (CQNode& c : held_cq) // the 8-bit nodes carry the same child references
+                        for (int j = 0; j < 4; ++j)
+                            if (c.child[j] != RT_REF_NONE && RT_REF_KIND(c.child[j]) == REF_QNODE) c.child[j] = make_ref(REF_QNODE, RT_REF_INDEX(c.child[j]) + shift);
+                    f.cqnodes.resize(shift, CQNode{});
+                    f.cqnodes.insert(f.cqnodes.end(), held_cq.begin(), held_cq.end());
+                    quantised_first = shift; quantised_count = held.size();
                     f.exact_first += shift;
                     f.exact_root = make_ref(REF_QNODE, RT_REF_INDEX(f.exact_root) + shift);
                     continue;
@@ -1133,12 +1136,20 @@ struct Flattener {
                 if (int rce = exact_cull_tree(root)) return rce;
         }
         auto measure_extent = [&]() {
-            f.q_extent = 0.0f;
-            for (const QNode& q : f.qnodes)
-                for (int j = 0; j < 4; ++j)
-                    if (q.child[j] != RT_REF_NONE)
-                        for (int a = 0; a < 3; ++a) f.q_extent = std::max(f.q_extent, std::max(std::fabs(q.lo[a][j]), std::fabs(q.hi[a][j])));
-            f.q_extent *= 1.0000001f;
+            const size_t total = f.qnodes.size();
+            const int parts = total >= (1u << 16) ? (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency())) : 1;
+            std::vector<float> ext((size_t)parts, 0.0f);
+            for_parts(parts, parts - 1, [&](int p) {
+                float e = 0.0f;
+                for (size_t i = total * (size_t)p / (size_t)parts; i < total * (size_t)(p + 1) / (size_t)parts; ++i) {
+                    const QNode& q = f.qnodes[i];
+                    for (int j = 0; j < 4; ++j)
+                        if (q.child[j] != RT_REF_NONE)
+                            for (int a = 0; a < 3; ++a) e = std::max(e, std::max(std::fabs(q.lo[a][j]), std::fabs(q.hi[a][j])));
+                }
+                ext[(size_t)p] = e;
+            });
+            f.q_extent = *std::max_element(ext.begin(), ext.end()) * 1.0000001f;
         };
         measure_extent();
         stage("4-wide trees");

@@ -26,6 +26,7 @@
 
 #define RT_REORDER_KERNELS
 #include "rt_internal.h"
+#include "host_parallel.h"
 #include "bvh_kernel.h"
 
 using namespace rt;
@@ -170,14 +171,14 @@ int upload(rt_scene* s, const std::vector<T, A>& v, const T** out) {
 }
 
 int finish_uploads(rt_scene* s) {
-    std::vector<std::future<hipError_t>> jobs;
-    for (const auto& u : s->pending_uploads)
-        jobs.push_back(std::async(std::launch::async, [s, u]() {
-            hipError_t e = hipSetDevice(s->device);
-            return e != hipSuccess ? e : hipMemcpy(u.dst, u.src, u.bytes, hipMemcpyHostToDevice);
-        }));
+    std::vector<hipError_t> results(s->pending_uploads.size(), hipSuccess);
+    for_parts((int)s->pending_uploads.size(), (int)s->pending_uploads.size() - 1, [&](int k) {
+        const rt_scene::PendingUpload& u = s->pending_uploads[(size_t)k];
+        hipError_t e = hipSetDevice(s->device); // (the device is a property of the thread)
+        results[(size_t)k] = e != hipSuccess ? e : hipMemcpy(u.dst, u.src, u.bytes, hipMemcpyHostToDevice);
+    });
     hipError_t first = hipSuccess;
-    for (auto& j : jobs) { const hipError_t e = j.get(); if (first == hipSuccess) first = e; }
+    for (const hipError_t e : results) if (first == hipSuccess) first = e;
     s->pending_uploads.clear();
     if (first != hipSuccess) return set_err(RT_E_HIP, std::string("upload of the scene arrays: ") + hipGetErrorString(first));
     return RT_OK;

@@ -114,7 +114,14 @@ def test_overlapping_allocation_free_calls_are_refused():
     for scene in (gpu, other):  # (a kernel's first launch in a process loads its code and blocks the host for that long)
         scene.closest_hit_device(small, hits2, 1000, seed=5, flags=0, stream=s1.cuda_stream, noalloc=True)
     torch.cuda.synchronize()
-    gpu.closest_hit_device(rays, hits, n, seed=5, flags=0, stream=s1.cuda_stream, noalloc=True)          # about half a millisecond of work
+    # some tens of milliseconds of other work in front of the call on its stream, so that the call's own work (about half
+    # a millisecond) is certainly still pending when the next call arrives, however slow this host is
+    a = torch.randn(4096, 4096, device=dev)
+    s1.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s1):
+        for _ in range(40):
+            a = (a @ a).clamp_(-1.0, 1.0)
+    gpu.closest_hit_device(rays, hits, n, seed=5, flags=0, stream=s1.cuda_stream, noalloc=True)
     with pytest.raises(rt.RtError) as err:
         other.closest_hit_device(small, hits2, 1000, seed=5, flags=0, stream=s2.cuda_stream, noalloc=True)
     assert err.value.code == F.RT_E_BUSY
