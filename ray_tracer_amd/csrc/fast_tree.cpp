@@ -10,9 +10,9 @@
 // reference is tested with the exact f64 intersector on the WHOLE triangle (triangle.rs:153-199), so a ray finds the
 // triangle's hit through whichever reference box it enters first, at the same t, bit for bit.
 //
-// On the 2^20-triangle soup (triangles as large as their spacing) a ray makes 27.4 node steps and 5.7 triangle tests in
-// this tree against 36.8 and 6.5 in the 4-wide collapse of the reference tree, at 1.35 references per triangle; on a
-// closed surface, where boxes hardly overlap, the gain is the heuristic's alone (12.9 against 14.0 node steps).
+// On the 2^20-triangle soup (triangles as large as their spacing) a ray makes 27.6 node steps and 5.7 triangle tests in
+// this tree against 36.8 and 6.5 in the 4-wide collapse of the reference tree, at 1.30 references per triangle; on a
+// closed surface, where boxes hardly overlap, the gain is the heuristic's alone (12.7 against 13.8 node steps).
 //
 // Three passes, each a recursion whose large subtrees run as tasks of their own: (1) the binary tree, partitioning the
 // references in place (a spatial split copies its node's references once); (2) which binary nodes become 4-wide nodes
