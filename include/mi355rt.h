@@ -314,8 +314,8 @@ int rt_closest_hit_device(rt_scene* scene, const rt_ray_batch* rays, uint64_t n,
  * *_device calls within those sizes only enqueue.  Waits for the device first. */
 int rt_scene_reserve(rt_scene* scene, uint64_t max_rays, uint64_t max_paths);
 
-/* No counterpart in the reference.  For callers that cannot allocate device memory while they call (code
- * under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): the same query as
+/* No counterpart in the reference.  For callers that cannot allocate device memory while they call (tight
+ * serving loops, harnesses that forbid hipMalloc, code that must not block on the allocator): the same query as
  * rt_closest_hit_device, same arguments and results, but the 4 bytes per ray of scratch that the general
  * traversal keeps between its two kernels live in a fixed 64 MiB array inside the library's code object
  * (one copy per GPU, held until the process ends) instead of a buffer grown with hipMalloc.
@@ -325,7 +325,12 @@ int rt_scene_reserve(rt_scene* scene, uint64_t max_rays, uint64_t max_paths);
  *     scenes, two threads) would race on it and must be serialised by the caller.  The library checks what it
  *     can see: a call on another stream than the previous one, while that one's work has not finished, returns
  *     RT_E_BUSY and enqueues nothing (calls on one stream follow each other and are always accepted; nothing is
- *     checked, or recorded, on a stream that is being captured into a graph). */
+ *     checked, or recorded, on a stream that is being captured into a graph);
+ *   - HIP graph capture: the call makes no allocation, synchronisation, event query or timing record, so it can be
+ *     captured; REPLAY has only been seen to work for worlds traced by the general kernels (a flat list of objects).
+ *     For a world that is one BVH over primitives a replayed call left most rays untraced with the ROCm 7.0 runtime
+ *     (the work counters' reset, a memset node, did not take effect on replay), and unwritten outputs then feed the
+ *     record completion.  Do not replay captured calls of this library; call it directly. */
 #define RT_NOALLOC_MAX_RAYS (1ull << 24)
 int rt_closest_hit_device_noalloc(rt_scene* scene, const rt_ray_batch* rays, uint64_t n,
                                   rt_hit_batch* hits, uint64_t seed, uint32_t flags,
