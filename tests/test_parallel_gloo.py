@@ -1,4 +1,4 @@
-"""Multi-process path on the CPU: world-size-2 gloo groups run the frame partition + sum-reduce of
+"""Multi-process path on the CPU: gloo groups of 2, 3 and 5 ranks run the frame partition + sum-reduce of
 ray_tracer_amd.parallel with the ORACLE as the per-rank renderer, and the result must equal the
 unsplit frame.  (The GPU renderer plugs into the same functions; its partition independence is
 covered by tests/test_gpu_render.py.)"""
@@ -82,11 +82,13 @@ def _worker(rank, world, port, mode, out_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["strata", "tiles"])
-def test_two_rank_render_equals_unsplit_frame(tmp_path, mode):
+@pytest.mark.parametrize("mode,world", [("strata", 2), ("tiles", 2), ("strata", 5), ("tiles", 3)])
+def test_multi_rank_render_equals_unsplit_frame(tmp_path, mode, world):
+    """World sizes 2, 3 and 5: with five ranks the accumulator's 1728 numbers do not divide into equal bands (the
+    reduce-scatter pads), and the 24 image rows of the tiles partition split unevenly over three."""
     import torch.multiprocessing as mp
-    out = str(tmp_path / f"r_{mode}.npy")
-    mp.spawn(_worker, args=(2, _free_port(), mode, out), nprocs=2, join=True)
+    out = str(tmp_path / f"r_{mode}_{world}.npy")
+    mp.spawn(_worker, args=(world, _free_port(), mode, out), nprocs=world, join=True)
     got, full, got5, part5, other5 = np.load(out)
     assert full.mean() > 1e-3
     assert np.allclose(np.nan_to_num(got), np.nan_to_num(full), rtol=1e-12, atol=1e-14)
