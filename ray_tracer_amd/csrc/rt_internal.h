@@ -188,6 +188,7 @@ struct rt_scene {
     int grid_blocks = 0;
     int fast_grid_blocks = 0;
     int fast_grid_blocks_prep = 0; // the same for launches on prepared rays (reorder.h), whose kernel variant fits more waves
+    int exact_grid_blocks = 0, exact_grid_blocks_prep = 0; // the same for the exact-cull variants of that kernel (more registers, fewer resident workgroups)
     int extend_blocks = 0, shade_blocks = 0, tail_blocks = 0;
     size_t fast_lds = 0;
     uint2* fast_spill = nullptr; // HBM overflow of the per-lane stacks: [entry][thread]
