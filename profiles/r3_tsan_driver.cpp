@@ -1,6 +1,6 @@
 // Host-only driver for a ThreadSanitizer run of the flattener and the tree builder (no GPU, no HIP):
 //   cd ray_tracer_amd/csrc && g++ -std=c++17 -O1 -g -fsanitize=thread -I. -I../../include flatten.cpp fast_tree.cpp ../../profiles/r3_tsan_driver.cpp -o /tmp/drv -pthread && /tmp/drv 300000
-// Result on the final build of round 3: two builds of a 300,000-triangle mesh (chunked binning, subtree tasks, the exact-cull
+// Result when it was last run (the build that produced profiles/r3_bench.json): two builds of a 300,000-triangle mesh (chunked binning, subtree tasks, the exact-cull
 // collapse beside them), no report.
 #include <cstdio>
 #include <cstdlib>
