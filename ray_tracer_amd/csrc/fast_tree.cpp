@@ -580,6 +580,7 @@ int build_fast_tree(const DTri* tris, FlatScene& f, std::vector<uint8_t>& qdepth
     B.packed = (wide + 4u) * sizeof(PNode) < (1ull << 32) && (leaves + 4u) * sizeof(PTri) < (1ull << 32);
     f.qnodes.reserve(first + wide + n);             // room for the collapses of the reference's tree behind this one (address space only)
     f.qnodes.resize(first + wide);
+    f.cqnodes.reserve(first + wide + n);
     f.cqnodes.resize(first + wide);
     qdepth.resize(first + wide);
     f.pnodes.clear(); f.ptris.clear();

@@ -788,6 +788,9 @@ struct Flattener {
         // the general kernel's nearest-first traversal enters the same tree at this BVH's root
         need_q[root] = res.stack_need;
         f.wnodes[root].qroot = res.root + 1;
+        // (the builder has counted it: no second walk over the tree's nodes when the scene's stack depth is worked out)
+        if (need_wide_memo.size() < f.qnodes.size()) need_wide_memo.resize(f.qnodes.size(), -1);
+        need_wide_memo[res.root] = res.stack_need;
         return RT_OK;
     }
     // The common case, a world that is a Mesh (a BVH declared over a range of triangles): the traversal-only tree needs
@@ -820,6 +823,7 @@ struct Flattener {
             return build_fast_tree(f.tris.data(), early.scene, early.depth, early.ids.data(), early.ids.size(), early.res, early.err);
         });
     }
+    bool need_memo_kept = false; // need_node already holds the binary nodes below the world's BVH root (filled while the traversal-only tree was being built)
     size_t quantised_first = 0, quantised_count = 0; // wide nodes whose 8-bit form exists already (the exact-cull tree, when it was built beside the traversal-only one)
     size_t fast_tree_first = 0, fast_tree_count = 0; // the traversal-only tree's nodes in qnodes (they come with their 8-bit and packed forms)
     double fast_ratio_sum = 0.0, fast_leaf_area = 0.0;
@@ -1096,6 +1100,12 @@ struct Flattener {
                     // (its 8-bit form too, with a few threads: the others are busy with the tree this one waits for)
                     RawVec<CQNode> held_cq(held.size());
                     for_parts(4, 3, [&](int p) { for (size_t i = held.size() * (size_t)p / 4; i < held.size() * (size_t)(p + 1) / 4; ++i) quantise_node(held[i], held_cq[i]); });
+                    // (and the stack need of the reference-order traversal below this root, a walk over every binary node:
+                    // nothing below the root depends on the trees still to come; the memo serves the final pass)
+                    need_node.assign(f.nodes.size(), -1);
+                    need_memo_kept = true;
+                    (void)need(f.nodes[root].left);
+                    if (f.nodes[root].right != f.nodes[root].left) (void)need(f.nodes[root].right);
                     if (int rcf = traversal_only_tree(root)) return rcf;
                     if (!f.fast_tree) {
                         // no such tree after all (coordinates its f32 boxes cannot hold): the collapse of the reference's
@@ -1181,7 +1191,7 @@ struct Flattener {
         }
         pack_fast_tree();
         stage("packed tree");
-        need_node.assign(f.nodes.size(), -1);
+        if (!need_memo_kept) need_node.assign(f.nodes.size(), -1);
         f.max_stack = (uint32_t)need(f.world) + 1;
         if (f.max_stack > (uint32_t)STACK_MAX) {
             // too deep for the general kernel's stack with 4-wide nodes (up to three deferred children per two
@@ -1192,6 +1202,7 @@ struct Flattener {
             f.max_stack = (uint32_t)need(f.world) + 1;
         }
         if (f.max_stack > (uint32_t)STACK_MAX) return fail(RT_E_TOO_LARGE, "scene needs a deeper traversal stack than the kernels carry (32 entries)");
+        stage("stack depth");
         return RT_OK;
     }
 };

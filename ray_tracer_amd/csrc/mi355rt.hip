@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -713,8 +714,10 @@ int rt_scene_create(const rt_scene_desc* desc, uint32_t flags, rt_scene** out) {
         if (e != hipSuccess) { delete s; return set_err(RT_E_HIP, std::string("no HIP device: ") + hipGetErrorString(e)); }
     }
     // large BVHs are built on the device (bvh_build.hip), in the same split order as the host recursion
+    const auto t_0 = std::chrono::steady_clock::now();
     int rc = flatten_scene(desc, s->flat, err, (flags & RT_SCENE_HOST_ONLY) ? 0 : s->tune.device_bvh_min, s->tune.fast_tree_min);
     if (rc) { delete s; return set_err(rc, err); }
+    const auto t_1 = std::chrono::steady_clock::now();
     if (flags & RT_SCENE_HOST_ONLY) {
         s->host_only = true;
         fill_host_dscene(s);
@@ -722,6 +725,9 @@ int rt_scene_create(const rt_scene_desc* desc, uint32_t flags, rt_scene** out) {
         rc = upload_scene(s);
         if (rc) { rt_scene_destroy(s); return rc; }
     }
+    if (s->tune.debug)
+        fprintf(stderr, "[mi355rt] rt_scene_create: flatten %.3f s, device arrays %.3f s (%.0f MB)\n", std::chrono::duration<double>(t_1 - t_0).count(),
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t_1).count(), (double)s->device_bytes / 1e6);
     *out = s;
     return RT_OK;
 }
